@@ -1,0 +1,422 @@
+"""CPU restatement of the F5-TTS flow-matching inference path (ORACLE -- test infrastructure only).
+
+This file is the *checker*, never the product: only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it.  ``eraxvif5tts_amd`` must not (and does not).
+
+It restates, as plain functional fp32 PyTorch over a flat ``{name: tensor}`` weight dict (names =
+the reference ``DiT.state_dict()`` keys), every arithmetic step of SURVEY.md section 8(a).  Each function
+cites the reference lines it follows (paths relative to /root/reference/src/f5_tts).
+
+Pinning: the reference ships no tests/golden vectors, so this restatement is pinned against outputs
+of the reference's own ``cfm.py`` / ``dit.py`` / ``modules.py`` run in the build container
+(``oracle/make_golden.py`` -> ``tests/golden/*.npz``; checked by ``tests/test_oracle_golden.py``).
+Three third-party boundaries are "parity unpinned" (restated from the published algorithms, source
+absent from the container): x_transformers RoPE, torchdiffeq fixed-grid solvers, vocos.
+Deviation from the shipped reference: attention dropout (modules.py:490, live at inference) is 0.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+LN_EPS = 1e-6
+
+
+# ----------------------------------------------------------------------------- small helpers
+def _lin(x, w, b=None):
+    y = x @ w.t()
+    return y if b is None else y + b
+
+
+def _layernorm(x, eps=LN_EPS):
+    mu = x.mean(dim=-1, keepdim=True)
+    xc = x - mu
+    var = (xc * xc).mean(dim=-1, keepdim=True)
+    return xc * torch.rsqrt(var + eps)
+
+
+def mish(x):
+    return x * torch.tanh(F.softplus(x))
+
+
+def gelu_tanh(x):
+    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x ** 3)))
+
+
+def gelu_erf(x):
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def silu(x):
+    return x * torch.sigmoid(x)
+
+
+# ----------------------------------------------------------------------------- a6: time grid
+def time_grid(steps, sway_sampling_coef=None, t_start=0.0, dtype=torch.float32):
+    """cfm.py:193-195: linspace(t_start,1,steps+1) then t += s*(cos(pi/2 t) - 1 + t)."""
+    t = torch.linspace(t_start, 1, steps + 1, dtype=dtype)
+    if sway_sampling_coef is not None:
+        t = t + sway_sampling_coef * (torch.cos(torch.pi / 2 * t) - 1 + t)
+    return t
+
+
+# ----------------------------------------------------------------------------- a10: time embedding
+def timestep_embedding(W, time):
+    """modules.py:149-161,721-731. time: [b] -> [b, dim].  sin half first, scale 1000, 256 freqs."""
+    half = 128
+    k = math.log(10000) / (half - 1)
+    freqs = torch.exp(torch.arange(half, dtype=torch.float32) * -k)
+    arg = 1000.0 * time[:, None].float() * freqs[None, :]
+    emb = torch.cat([arg.sin(), arg.cos()], dim=-1).to(time.dtype)
+    h = silu(_lin(emb, W["time_embed.time_mlp.0.weight"], W["time_embed.time_mlp.0.bias"]))
+    return _lin(h, W["time_embed.time_mlp.2.weight"], W["time_embed.time_mlp.2.bias"])
+
+
+# ----------------------------------------------------------------------------- a11/a12: text embedding
+def text_pos_table(dim, n_pos, theta=10000.0):
+    """modules.py:196-207 precompute_freqs_cis: [cos | sin] (cos first), theta_j = theta^(-2j/dim)."""
+    inv = 1.0 / (theta ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim))
+    ang = torch.outer(torch.arange(n_pos).float(), inv)
+    return torch.cat([ang.cos(), ang.sin()], dim=-1)
+
+
+def grn(x, gamma, beta):
+    """modules.py:225-234: L2 norm over the *sequence* axis, divided by its channel mean."""
+    gx = torch.sqrt((x * x).sum(dim=1, keepdim=True))
+    nx = gx / (gx.mean(dim=-1, keepdim=True) + 1e-6)
+    return gamma * (x * nx) + beta + x
+
+
+def convnext_v2_block(W, pre, x):
+    """modules.py:241-269. x: [b, n, d]."""
+    d = x.shape[-1]
+    y = F.conv1d(x.transpose(1, 2), W[pre + "dwconv.weight"], W[pre + "dwconv.bias"], padding=3, groups=d)
+    y = y.transpose(1, 2)
+    y = _layernorm(y) * W[pre + "norm.weight"] + W[pre + "norm.bias"]
+    y = gelu_erf(_lin(y, W[pre + "pwconv1.weight"], W[pre + "pwconv1.bias"]))
+    y = grn(y, W[pre + "grn.gamma"], W[pre + "grn.beta"])
+    y = _lin(y, W[pre + "pwconv2.weight"], W[pre + "pwconv2.bias"])
+    return x + y
+
+
+def text_embedding(W, cfg, text, seq_len, drop_text=False):
+    """dit.py:49-79. text: int [b, nt] with -1 padding -> [b, seq_len, text_dim]."""
+    ids = text + 1
+    ids = ids[:, :seq_len]
+    ids = F.pad(ids, (0, seq_len - ids.shape[1]), value=0)
+    filler = ids == 0  # computed BEFORE drop_text zeroing (dit.py:54-58)
+    if drop_text:
+        ids = torch.zeros_like(ids)
+    x = W["text_embed.text_embed.weight"][ids]
+    n_conv = cfg.get("conv_layers", 0)
+    if n_conv > 0:
+        pos = torch.arange(seq_len).clamp(max=4095)  # modules.py:210-219, batch_start = 0
+        x = x + text_pos_table(x.shape[-1], 4096)[pos][None]
+        mp = cfg.get("text_mask_padding", True)
+        if mp:
+            x = x.masked_fill(filler[..., None], 0.0)
+        for i in range(n_conv):
+            x = convnext_v2_block(W, f"text_embed.text_blocks.{i}.", x)
+            if mp:
+                x = x.masked_fill(filler[..., None], 0.0)
+    return x
+
+
+# ----------------------------------------------------------------------------- a13: input embedding
+def conv_pos_embed(W, x):
+    """modules.py:167-190 (called with mask=None from dit.py:96): 2x [grouped conv k=31 g=16 -> Mish]."""
+    y = x.transpose(1, 2)
+    for i in (0, 2):
+        y = mish(F.conv1d(y, W[f"input_embed.conv_pos_embed.conv1d.{i}.weight"],
+                          W[f"input_embed.conv_pos_embed.conv1d.{i}.bias"], padding=15, groups=16))
+    return y.transpose(1, 2)
+
+
+def input_embedding(W, x, cond, text_embed, drop_audio_cond=False):
+    """dit.py:91-97: proj(cat(x, cond, text)) then x + conv_pos_embed(x)."""
+    if drop_audio_cond:
+        cond = torch.zeros_like(cond)
+    h = _lin(torch.cat([x, cond, text_embed], dim=-1), W["input_embed.proj.weight"], W["input_embed.proj.bias"])
+    return conv_pos_embed(W, h) + h
+
+
+# ----------------------------------------------------------------------------- a14/a18: RoPE
+def rope_angles(seq_len, dim_head=64, base=10000.0):
+    """x_transformers RotaryEmbedding.forward_from_seq_len (dit.py:134,215): angle[p, j] = p * base^(-2j/dim)."""
+    inv = 1.0 / (base ** (torch.arange(0, dim_head, 2).float() / dim_head))
+    return torch.outer(torch.arange(seq_len).float(), inv)  # [n, dim_head/2]
+
+
+def apply_rope(t, ang):
+    """x_transformers apply_rotary_pos_emb on [b, h, n, d]: adjacent pairs (x0,x1)->(x0 c - x1 s, x1 c + x0 s)."""
+    c, s = ang.cos()[None, None], ang.sin()[None, None]
+    x0, x1 = t[..., 0::2].float(), t[..., 1::2].float()
+    out = torch.stack([x0 * c - x1 * s, x1 * c + x0 * s], dim=-1).flatten(-2)
+    return out.to(t.dtype)
+
+
+# ----------------------------------------------------------------------------- a15-a19: DiT block
+def attention(W, pre, cfg, x, mask, ang):
+    """modules.py:442-503 with dropout_p forced to 0 (deviation stated in the module docstring)."""
+    b, n, _ = x.shape
+    h, dh = cfg["heads"], cfg.get("dim_head", 64)
+    q = _lin(x, W[pre + "to_q.weight"], W[pre + "to_q.bias"]).view(b, n, h, dh).transpose(1, 2)
+    k = _lin(x, W[pre + "to_k.weight"], W[pre + "to_k.bias"]).view(b, n, h, dh).transpose(1, 2)
+    v = _lin(x, W[pre + "to_v.weight"], W[pre + "to_v.bias"]).view(b, n, h, dh).transpose(1, 2)
+    pn = cfg.get("pe_attn_head", None)
+    pn = h if pn is None else pn
+    q = torch.cat([apply_rope(q[:, :pn], ang), q[:, pn:]], dim=1)
+    k = torch.cat([apply_rope(k[:, :pn], ang), k[:, pn:]], dim=1)
+    s = torch.einsum("bhid,bhjd->bhij", q, k) / math.sqrt(dh)
+    if mask is not None:
+        s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    o = torch.einsum("bhij,bhjd->bhid", p, v).transpose(1, 2).reshape(b, n, h * dh)
+    o = _lin(o, W[pre + "to_out.0.weight"], W[pre + "to_out.0.bias"])
+    if mask is not None:
+        o = o.masked_fill(~mask[..., None], 0.0)
+    return o
+
+
+def dit_block(W, i, cfg, x, t_emb, mask, ang, trace=None):
+    """modules.py:627-641 + AdaLayerNorm modules.py:310-315 (chunk order shift,scale,gate x {msa,mlp})."""
+    pre = f"transformer_blocks.{i}."
+    emb = _lin(silu(t_emb), W[pre + "attn_norm.linear.weight"], W[pre + "attn_norm.linear.bias"])
+    sh_a, sc_a, g_a, sh_m, sc_m, g_m = emb.chunk(6, dim=1)
+    n1 = _layernorm(x) * (1 + sc_a[:, None]) + sh_a[:, None]
+    a = attention(W, pre + "attn.", cfg, n1, mask, ang)
+    x = x + g_a[:, None] * a
+    n2 = _layernorm(x) * (1 + sc_m[:, None]) + sh_m[:, None]
+    f = _lin(gelu_tanh(_lin(n2, W[pre + "ff.ff.0.0.weight"], W[pre + "ff.ff.0.0.bias"])),
+             W[pre + "ff.ff.2.weight"], W[pre + "ff.ff.2.bias"])
+    y = x + g_m[:, None] * f
+    if trace is not None:
+        trace.update({f"blk{i}.n1": n1, f"blk{i}.attn": a, f"blk{i}.x_mid": x, f"blk{i}.n2": n2, f"blk{i}.out": y})
+    return y
+
+
+# ----------------------------------------------------------------------------- a9/a20: DiT forward
+def dit_forward(W, cfg, x, cond, text, time, drop_audio_cond, drop_text, mask=None, text_embed=None, trace=None):
+    """dit.py:185-233.  ``text_embed`` may be passed to mimic the cache (dit.py:202-210)."""
+    b, n, _ = x.shape
+    if time.ndim == 0:
+        time = time.repeat(b)
+    t_emb = timestep_embedding(W, time)
+    if text_embed is None:
+        text_embed = text_embedding(W, cfg, text, n, drop_text=drop_text)
+    h = input_embedding(W, x, cond, text_embed, drop_audio_cond=drop_audio_cond)
+    ang = rope_angles(n, cfg.get("dim_head", 64))
+    if trace is not None:
+        trace.update({"t_emb": t_emb, "text_embed": text_embed, "input_embed": h})
+    for i in range(cfg["depth"]):
+        h = dit_block(W, i, cfg, h, t_emb, mask, ang, trace=trace)
+    emb = _lin(silu(t_emb), W["norm_out.linear.weight"], W["norm_out.linear.bias"])
+    scale, shift = emb.chunk(2, dim=1)  # modules.py:333: (scale, shift) order
+    h = _layernorm(h) * (1 + scale)[:, None] + shift[:, None]
+    out = _lin(h, W["proj_out.weight"], W["proj_out.bias"])
+    if trace is not None:
+        trace.update({"final_norm": h, "out": out})
+    return out
+
+
+# ----------------------------------------------------------------------------- a4-a8, a21: sampler
+def lens_to_mask(lens, length=None):
+    """utils.py:42-47."""
+    length = int(lens.max()) if length is None else length
+    return torch.arange(length)[None, :] < lens[:, None]
+
+
+def sample(W, cfg, cond, text, duration, *, lens=None, steps=32, cfg_strength=1.0, sway_sampling_coef=None,
+           seed=None, max_duration=4096, y0=None, method="euler", no_ref_audio=False, return_trajectory=True):
+    """cfm.py:82-208 with cond given as mel [b, nc, 100] and text as id tensor [b, nt] (-1 padded).
+
+    ``y0`` (zero-padded [b, N, 100]) overrides the per-sample ``manual_seed(seed); randn`` of cfm.py:178-183.
+    """
+    cond = cond.float()
+    b, nc, nmel = cond.shape
+    if lens is None:
+        lens = torch.full((b,), nc, dtype=torch.long)
+    cond_mask = lens_to_mask(lens)
+    if isinstance(duration, int):
+        duration = torch.full((b,), duration, dtype=torch.long)
+    duration = torch.maximum(torch.maximum((text != -1).sum(dim=-1), lens) + 1, duration).clamp(max=max_duration)
+    N = int(duration.max())
+    cond = F.pad(cond, (0, 0, 0, N - nc), value=0.0)
+    if no_ref_audio:
+        cond = torch.zeros_like(cond)
+    cond_mask = F.pad(cond_mask, (0, N - cond_mask.shape[-1]), value=False)[..., None]
+    step_cond = torch.where(cond_mask, cond, torch.zeros_like(cond))
+    mask = lens_to_mask(duration) if b > 1 else None  # cfm.py:152-155
+
+    if y0 is None:
+        rows = []
+        for d in duration.tolist():
+            if seed is not None:
+                torch.manual_seed(seed)
+            rows.append(F.pad(torch.randn(d, nmel), (0, 0, 0, N - d)))
+        y0 = torch.stack(rows)
+
+    te_c = text_embedding(W, cfg, text, N, drop_text=False)
+    te_u = text_embedding(W, cfg, text, N, drop_text=True)
+
+    def fn(t, x):
+        pred = dit_forward(W, cfg, x, step_cond, text, t, False, False, mask=mask, text_embed=te_c)
+        if cfg_strength < 1e-5:
+            return pred
+        null = dit_forward(W, cfg, x, step_cond, text, t, True, True, mask=mask, text_embed=te_u)
+        return pred + (pred - null) * cfg_strength
+
+    t = time_grid(steps, sway_sampling_coef)
+    y = y0
+    traj = [y0]
+    for t0, t1 in zip(t[:-1], t[1:]):  # torchdiffeq fixed grid (a7)
+        dt = t1 - t0
+        if method == "euler":
+            y = y + dt * fn(t0, y)
+        elif method == "midpoint":
+            half = 0.5 * dt
+            y = y + dt * fn(t0 + half, y + fn(t0, y) * half)
+        else:
+            raise ValueError(method)
+        if return_trajectory:
+            traj.append(y)
+    out = torch.where(cond_mask, cond, y)  # cfm.py:200-202 (rows past duration are NOT zeroed)
+    return out, (torch.stack(traj) if return_trajectory else None)
+
+
+# ----------------------------------------------------------------------------- a3: mel extraction
+def hz_to_mel_htk(f):
+    return 2595.0 * math.log10(1.0 + f / 700.0)
+
+
+def mel_filterbank(n_freqs=513, n_mels=100, sr=24000, f_min=0.0, f_max=None):
+    """torchaudio.functional.melscale_fbanks(norm=None, mel_scale='htk') restated (unpinned: torchaudio absent)."""
+    f_max = sr / 2 if f_max is None else f_max
+    all_freqs = torch.linspace(0, sr // 2, n_freqs)
+    m_pts = torch.linspace(hz_to_mel_htk(f_min), hz_to_mel_htk(f_max), n_mels + 2)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts[None, :] - all_freqs[:, None]
+    down = -slopes[:, :-2] / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return torch.clamp(torch.minimum(down, up), min=0.0)  # [n_freqs, n_mels]
+
+
+def mel_spectrogram(wave, n_fft=1024, hop=256, win=1024, n_mels=100, sr=24000):
+    """modules.py:75-101: MelSpectrogram(power=1, center=True, reflect pad, periodic hann) -> clamp(1e-5).log()."""
+    window = torch.hann_window(win, periodic=True)
+    spec = torch.stft(wave, n_fft, hop_length=hop, win_length=win, window=window, center=True,
+                      pad_mode="reflect", normalized=False, onesided=True, return_complex=True).abs()
+    mel = torch.matmul(spec.transpose(-1, -2), mel_filterbank(n_fft // 2 + 1, n_mels, sr)).transpose(-1, -2)
+    return mel.clamp(min=1e-5).log()  # [b, n_mels, nw//hop + 1]
+
+
+# ----------------------------------------------------------------------------- a22: Vocos (unpinned)
+def vocos_backbone(V, mel):
+    """vocos VocosBackbone (source absent; restated): conv k7 -> LN -> 8x ConvNeXt(layer-scale) -> LN."""
+    x = F.conv1d(mel, V["backbone.embed.weight"], V["backbone.embed.bias"], padding=3).transpose(1, 2)
+    x = _layernorm(x) * V["backbone.norm.weight"] + V["backbone.norm.bias"]
+    i = 0
+    while f"backbone.convnext.{i}.dwconv.weight" in V:
+        p = f"backbone.convnext.{i}."
+        d = x.shape[-1]
+        y = F.conv1d(x.transpose(1, 2), V[p + "dwconv.weight"], V[p + "dwconv.bias"], padding=3, groups=d).transpose(1, 2)
+        y = _layernorm(y) * V[p + "norm.weight"] + V[p + "norm.bias"]
+        y = _lin(gelu_erf(_lin(y, V[p + "pwconv1.weight"], V[p + "pwconv1.bias"])), V[p + "pwconv2.weight"], V[p + "pwconv2.bias"])
+        x = x + V[p + "gamma"] * y
+        i += 1
+    return _layernorm(x) * V["backbone.final_layer_norm.weight"] + V["backbone.final_layer_norm.bias"]
+
+
+def istft_center(spec_re, spec_im, n_fft=1024, hop=256):
+    """torch.istft(center=True, hann periodic window) written out: irfft -> window -> overlap-add ->
+    divide by overlap-added window^2 -> trim n_fft/2 each side.  spec: [b, n_fft/2+1, T] -> [b, (T-1)*hop]."""
+    b, _, T = spec_re.shape
+    window = torch.hann_window(n_fft, periodic=True)
+    frames = torch.fft.irfft(torch.complex(spec_re, spec_im), n=n_fft, dim=1) * window[None, :, None]
+    out_len = n_fft + hop * (T - 1)
+    y = torch.zeros(b, out_len)
+    env = torch.zeros(out_len)
+    w2 = window * window
+    for t in range(T):
+        y[:, t * hop: t * hop + n_fft] += frames[:, :, t]
+        env[t * hop: t * hop + n_fft] += w2
+    half = n_fft // 2
+    return y[:, half: out_len - half] / env[half: out_len - half]
+
+
+def vocos_decode(V, mel):
+    """vocos Vocos.decode (wrapper.py:524): backbone -> Linear(512->1026) -> exp/clip(1e2), cos/sin -> ISTFT."""
+    h = _lin(vocos_backbone(V, mel), V["head.out.weight"], V["head.out.bias"]).transpose(1, 2)
+    mag, ph = h.chunk(2, dim=1)
+    mag = torch.exp(mag).clamp(max=1e2)
+    return istft_center(mag * torch.cos(ph), mag * torch.sin(ph))
+
+
+# ----------------------------------------------------------------------------- synthetic weights
+def dit_param_shapes(cfg, vocab_size, mel_dim=100):
+    """Names/shapes of DiT.state_dict() for a given arch dict."""
+    D, L, td = cfg["dim"], cfg["depth"], cfg.get("text_dim") or mel_dim
+    inner = cfg["heads"] * cfg.get("dim_head", 64)
+    ff = int(D * cfg.get("ff_mult", 4))
+    s = {"time_embed.time_mlp.0.weight": (D, 256), "time_embed.time_mlp.0.bias": (D,),
+         "time_embed.time_mlp.2.weight": (D, D), "time_embed.time_mlp.2.bias": (D,),
+         "text_embed.text_embed.weight": (vocab_size + 1, td)}
+    for i in range(cfg.get("conv_layers", 0)):
+        p = f"text_embed.text_blocks.{i}."
+        s.update({p + "dwconv.weight": (td, 1, 7), p + "dwconv.bias": (td,), p + "norm.weight": (td,), p + "norm.bias": (td,),
+                  p + "pwconv1.weight": (2 * td, td), p + "pwconv1.bias": (2 * td,), p + "grn.gamma": (1, 1, 2 * td),
+                  p + "grn.beta": (1, 1, 2 * td), p + "pwconv2.weight": (td, 2 * td), p + "pwconv2.bias": (td,)})
+    s.update({"input_embed.proj.weight": (D, 2 * mel_dim + td), "input_embed.proj.bias": (D,)})
+    for i in (0, 2):
+        s.update({f"input_embed.conv_pos_embed.conv1d.{i}.weight": (D, D // 16, 31), f"input_embed.conv_pos_embed.conv1d.{i}.bias": (D,)})
+    for i in range(L):
+        p = f"transformer_blocks.{i}."
+        s.update({p + "attn_norm.linear.weight": (6 * D, D), p + "attn_norm.linear.bias": (6 * D,)})
+        for nm in ("to_q", "to_k", "to_v"):
+            s.update({p + f"attn.{nm}.weight": (inner, D), p + f"attn.{nm}.bias": (inner,)})
+        s.update({p + "attn.to_out.0.weight": (D, inner), p + "attn.to_out.0.bias": (D,),
+                  p + "ff.ff.0.0.weight": (ff, D), p + "ff.ff.0.0.bias": (ff,), p + "ff.ff.2.weight": (D, ff), p + "ff.ff.2.bias": (D,)})
+    s.update({"norm_out.linear.weight": (2 * D, D), "norm_out.linear.bias": (2 * D,),
+              "proj_out.weight": (mel_dim, D), "proj_out.bias": (mel_dim,)})
+    return s
+
+
+def random_dit_weights(cfg, vocab_size, seed=0, mel_dim=100):
+    """Seeded synthetic weights (no checkpoint exists offline): N(0, 1/fan_in)-style for matrices, small biases,
+    zero-init tensors of the reference re-randomised so every path is live."""
+    g = torch.Generator().manual_seed(seed)
+    W = {}
+    for name, shape in dit_param_shapes(cfg, vocab_size, mel_dim).items():
+        if name.endswith("norm.weight"):
+            W[name] = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif name.endswith("bias") or "grn." in name:
+            W[name] = 0.05 * torch.randn(shape, generator=g)
+        elif name == "text_embed.text_embed.weight":
+            W[name] = torch.randn(shape, generator=g)
+        elif "attn_norm.linear.weight" in name or "norm_out.linear.weight" in name:
+            W[name] = torch.randn(shape, generator=g) * (0.5 / math.sqrt(shape[1]))
+        else:
+            fan_in = math.prod(shape[1:])
+            W[name] = torch.randn(shape, generator=g) / math.sqrt(fan_in)
+    return W
+
+
+def random_vocos_weights(seed=0, dim=512, inter=1536, layers=8, n_mels=100, n_fft=1024):
+    g = torch.Generator().manual_seed(seed)
+    V = {"backbone.embed.weight": torch.randn(dim, n_mels, 7, generator=g) / math.sqrt(n_mels * 7),
+         "backbone.embed.bias": 0.05 * torch.randn(dim, generator=g),
+         "backbone.norm.weight": 1 + 0.1 * torch.randn(dim, generator=g), "backbone.norm.bias": 0.05 * torch.randn(dim, generator=g),
+         "backbone.final_layer_norm.weight": 1 + 0.1 * torch.randn(dim, generator=g),
+         "backbone.final_layer_norm.bias": 0.05 * torch.randn(dim, generator=g),
+         "head.out.weight": torch.randn(n_fft + 2, dim, generator=g) / math.sqrt(dim), "head.out.bias": 0.05 * torch.randn(n_fft + 2, generator=g)}
+    for i in range(layers):
+        p = f"backbone.convnext.{i}."
+        V.update({p + "dwconv.weight": torch.randn(dim, 1, 7, generator=g) / math.sqrt(7), p + "dwconv.bias": 0.05 * torch.randn(dim, generator=g),
+                  p + "norm.weight": 1 + 0.1 * torch.randn(dim, generator=g), p + "norm.bias": 0.05 * torch.randn(dim, generator=g),
+                  p + "pwconv1.weight": torch.randn(inter, dim, generator=g) / math.sqrt(dim), p + "pwconv1.bias": 0.05 * torch.randn(inter, generator=g),
+                  p + "pwconv2.weight": torch.randn(dim, inter, generator=g) / math.sqrt(inter), p + "pwconv2.bias": 0.05 * torch.randn(dim, generator=g),
+                  p + "gamma": 0.125 + 0.02 * torch.randn(dim, generator=g)})
+    return V

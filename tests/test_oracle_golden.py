@@ -1,0 +1,95 @@
+"""The CPU oracle (oracle/cpu_ref.py) against golden vectors produced by the REAL reference code
+(oracle/make_golden.py, run in the build container).  fp32 vs fp32: tolerance 2e-5 rel-L2 (op order only)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_arch, golden_weights, load_golden, rel_l2
+from oracle import cpu_ref
+
+TOL = 2e-5
+
+
+@pytest.mark.parametrize("name", ["tiny_base", "tiny_v1"])
+def test_sample_end_to_end(name):
+    z = load_golden(name)
+    cfg, W = golden_arch(z), golden_weights(z)
+    out, traj = cpu_ref.sample(W, cfg, torch.from_numpy(z["cond"]), torch.from_numpy(z["text"]), torch.from_numpy(z["duration"]),
+                               lens=torch.from_numpy(z["lens"]), steps=int(z["steps"]), cfg_strength=float(z["cfg_strength"]),
+                               sway_sampling_coef=float(z["sway"]), seed=int(z["seed"]))
+    assert torch.equal(traj[0], torch.from_numpy(z["y0"]))  # CPU mt19937 stream reproduces cfm.py:178-183
+    assert rel_l2(traj, z["traj"]) < TOL
+    assert rel_l2(out, z["out"]) < TOL
+    # rows past each sample's duration are not zeroed by the reference (cfm.py:200-202)
+    assert out.shape == z["out"].shape
+
+
+@pytest.mark.parametrize("name", ["tiny_base", "tiny_v1"])
+@pytest.mark.parametrize("branch", ["trc", "tru"])
+def test_forward_stage_traces(name, branch):
+    z = load_golden(name)
+    cfg, W = golden_arch(z), golden_weights(z)
+    drop = branch == "tru"
+    mask = cpu_ref.lens_to_mask(torch.from_numpy(z["duration"]))
+    trace = {}
+    cpu_ref.dit_forward(W, cfg, torch.from_numpy(z["trace_x"]), torch.from_numpy(z["trace_cond"]), torch.from_numpy(z["text"]),
+                        torch.from_numpy(z["trace_t"]), drop, drop, mask=mask, trace=trace)
+    for key in ["t_emb", "text_embed", "input_embed", "blk0.n1", "blk0.attn", "blk0.out", "blk1.n1", "blk1.attn", "blk1.out",
+                "final_norm", "out"]:
+        assert rel_l2(trace[key], z[f"{branch}.{key}"]) < TOL, key
+
+
+def test_b1_midpoint_and_cfg0():
+    z = load_golden("tiny_b1_midpoint")
+    cfg, W = golden_arch(z), golden_weights(z)
+    for tag, cs in (("cfg0", 0.0), ("cfg2", 2.0)):
+        out, traj = cpu_ref.sample(W, cfg, torch.from_numpy(z["cond"]), torch.from_numpy(z["text"]), int(z["duration"]),
+                                   steps=int(z["steps"]), cfg_strength=cs, sway_sampling_coef=float(z["sway"]), seed=int(z["seed"]),
+                                   method="midpoint")
+        assert out.shape[1] == 41  # duration rule: max(text_len, lens) + 1 beats the requested 30 (cfm.py:132-135)
+        assert rel_l2(traj, z["traj_" + tag]) < TOL
+        assert rel_l2(out, z["out_" + tag]) < TOL
+
+
+def test_true_size_base_forward():
+    """F5TTS_Base dims (1024 x 22 layers, pe_attn_head=1): weights regenerated from the seed on this machine."""
+    z = load_golden("base_fwd")
+    cfg = dict(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, text_mask_padding=False, conv_layers=4, pe_attn_head=1)
+    W = cpu_ref.random_dit_weights(cfg, int(z["vocab"]), seed=int(z["seed"]))
+    for drop, key in ((False, "out_c"), (True, "out_u")):
+        out = cpu_ref.dit_forward(W, cfg, torch.from_numpy(z["x"]), torch.from_numpy(z["cond"]), torch.from_numpy(z["text"]),
+                                  torch.from_numpy(z["t"]), drop, drop, mask=torch.from_numpy(z["mask"]))
+        assert rel_l2(out, z[key]) < 5e-5, key
+
+
+def test_time_grid_sway():
+    t = cpu_ref.time_grid(32, -1.0)
+    ref = 1 - torch.cos(torch.pi / 2 * torch.linspace(0, 1, 33))
+    assert torch.allclose(t, ref, atol=1e-6)
+    assert float(t[0]) == 0.0 and abs(float(t[-1]) - 1.0) < 1e-6
+
+
+def test_mel_and_istft_consistency():
+    """a3/a22 are 'parity unpinned' (torchaudio / vocos absent): cross-check the restatements against
+    independent formulations (scipy STFT; torch.istft)."""
+    import scipy.signal
+    g = torch.Generator().manual_seed(0)
+    wav = torch.randn(1, 24000 // 4, generator=g) * 0.1
+    mel = cpu_ref.mel_spectrogram(wav)
+    assert mel.shape == (1, 100, wav.shape[1] // 256 + 1)
+    x = np.pad(wav[0].numpy().astype(np.float64), 512, mode="reflect")
+    _, _, Z = scipy.signal.stft(x, window=scipy.signal.get_window("hann", 1024, fftbins=True), nperseg=1024, noverlap=768,
+                                nfft=1024, boundary=None, padded=False, scaling="spectrum")
+    mag = np.abs(Z) * scipy.signal.get_window("hann", 1024, fftbins=True).sum()
+    fb = cpu_ref.mel_filterbank().double().numpy()
+    ref = np.log(np.clip(fb.T @ mag, 1e-5, None))
+    assert np.abs(mel[0].numpy() - ref).max() < 2e-3
+    # ISTFT restatement vs torch.istft
+    T = 9
+    re, im = torch.randn(2, 513, T, generator=g), torch.randn(2, 513, T, generator=g)
+    im[:, 0] = 0
+    im[:, -1] = 0
+    mine = cpu_ref.istft_center(re, im)
+    ref = torch.istft(torch.complex(re, im), 1024, hop_length=256, win_length=1024, window=torch.hann_window(1024), center=True)
+    assert mine.shape == ref.shape == (2, (T - 1) * 256)
+    assert torch.allclose(mine, ref, atol=1e-5)
