@@ -1,0 +1,128 @@
+"""ctypes binding of libf5hip.so (C ABI: include/f5hip.h).  Fails loudly when the library or the GPU is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be imported first: libf5hip resolves libamdhip64.so.7 to the runtime torch already loaded)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libf5hip.so")
+
+F5_PREC_BF16, F5_PREC_FP32 = 0, 1
+F5_ODE_EULER, F5_ODE_MIDPOINT = 0, 1
+ACT = {"none": 0, "gelu_tanh": 1, "gelu_erf": 2, "mish": 3}
+
+
+class F5HipError(RuntimeError):
+    pass
+
+
+class DitConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dim", "depth", "heads", "dim_head", "ff_inner", "mel_dim", "text_num_embeds", "text_dim",
+                                         "conv_layers", "text_mask_padding", "pe_attn_head", "qk_norm", "long_skip", "precision")]
+
+
+class VocosConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_mels", "dim", "inter_dim", "layers", "n_fft", "hop")]
+
+
+_P, _I, _F = C.c_void_p, C.c_int, C.c_float
+_PROTOS = {
+    "f5_last_error": (C.c_char_p, []),
+    "f5_version": (_I, []),
+    "f5_device_count": (_I, [C.c_char_p]),
+    "f5_model_create": (_I, [C.POINTER(DitConfig), C.POINTER(_P)]),
+    "f5_model_set_tensor": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I]),
+    "f5_model_has_tensor": (_I, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
+    "f5_model_finalize": (_I, [_P]),
+    "f5_model_destroy": (_I, [_P]),
+    "f5_plan_create": (_I, [_P, _I, _I, _I, C.POINTER(_P)]),
+    "f5_plan_destroy": (_I, [_P]),
+    "f5_plan_workspace_bytes": (C.c_int64, [_P]),
+    "f5_sample": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _F, _I, _P, _P, _I, _P]),
+    "f5_text_embed": (_I, [_P, _I, _I, _P, _I, _I, _P, _P]),
+    "f5_dit_forward": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
+    "f5_plan_set_tap": (_I, [_P, C.c_char_p, _P]),
+    "f5_plan_set_option": (_I, [_P, C.c_char_p, _I]),
+    "f5_op_linear": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
+    "f5_op_layernorm_modulate": (_I, [_I, _I, _P, _P, _P, _P, _P]),
+    "f5_op_attention": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "f5_op_conv_pos_embed": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "f5_vocoder_create": (_I, [C.POINTER(VocosConfig), C.POINTER(_P)]),
+    "f5_vocoder_set_tensor": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I]),
+    "f5_vocoder_has_tensor": (_I, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
+    "f5_vocoder_finalize": (_I, [_P]),
+    "f5_vocoder_destroy": (_I, [_P]),
+    "f5_vocoder_decode": (_I, [_P, _I, _I, _P, _P, _P]),
+    "f5_vocoder_istft_head": (_I, [_P, _I, _I, _P, _P, _P]),
+}
+EXPORTS = tuple(_PROTOS)
+
+_lib = None
+
+
+def load(build_if_missing: bool = False):
+    """Load libf5hip.so (no compute).  Raises F5HipError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if build_if_missing:
+            from . import build as _b
+            _b.build(verbose=False)
+        else:
+            raise F5HipError(f"{LIB_PATH} not found: build it with `python -m eraxvif5tts_amd.build` (hipcc, gfx950). "
+                             "There is no CPU / eager-PyTorch fallback for the hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().f5_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        raise F5HipError(f"libf5hip {what} failed (code {rc}): {last_error()}")
+
+
+def require_gpu():
+    """The product path needs a real MI355X; anything else is an error, never a silent fallback."""
+    lib = load()
+    if not torch.cuda.is_available():
+        raise F5HipError("no ROCm device visible to PyTorch: the HIP hot path cannot run (no CPU fallback)")
+    name = C.create_string_buffer(64)
+    if lib.f5_device_count(name) <= 0:
+        raise F5HipError("no gfx950 (MI355X) device usable by libf5hip")
+    return name.value.decode()
+
+
+def ptr(t):
+    """Device/host pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "libf5hip takes contiguous tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def set_tensors(handle, setter, has, state: dict):
+    """Upload every tensor of `state` the native handle knows (strict=False semantics); returns the names used."""
+    lib = load()
+    used = []
+    for name, t in state.items():
+        if not getattr(lib, has)(handle, name.encode(), None):
+            continue
+        h = t.detach().to("cpu", torch.float32).contiguous()
+        shape = (C.c_int64 * h.ndim)(*h.shape)
+        check(getattr(lib, setter)(handle, name.encode(), C.c_void_p(h.data_ptr()), shape, h.ndim), f"set_tensor({name})")
+        used.append(name)
+    return used

@@ -1,0 +1,449 @@
+// elementwise.hip -- HBM-bound kernels of the DiT path: LayerNorm/modulate, ConvNeXt depthwise conv + LN, GRN,
+// embedding gather, timestep embedding, small-M fp32 linears (AdaLN modulation), packing, CFG + ODE step.
+// All row-wise kernels use one 64-lane wavefront per row with 16-byte vector accesses and wave-shuffle reductions.
+#include "kernels.h"
+
+// ----------------------------------------------------------------------------- LayerNorm (+ modulation)
+template <typename TO, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, int rows, int dim, const float* __restrict__ mul,
+                                                        const float* __restrict__ add, int mod_bstride, int rows_per_batch, float add_one,
+                                                        TO* __restrict__ out, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * ldx;
+    const int nvec = dim >> 2;  // dim % 4 == 0
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+            v[i] = *reinterpret_cast<const f32x4*>(xr + c * 4);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)dim + 1e-6f);
+    const size_t moff = (size_t)(row / rows_per_batch) * mod_bstride;
+    TO* orow = out + (size_t)row * ldo;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+            const f32x4 m4 = *reinterpret_cast<const f32x4*>(mul + moff + c * 4);
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(add + moff + c * 4);
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * (add_one + m4[e]) + a4[e];
+            if constexpr (sizeof(TO) == 2) {
+                *reinterpret_cast<bf16x4*>(orow + c * 4) = bf16x4{(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+            } else {
+                *reinterpret_cast<f32x4*>(orow + c * 4) = f32x4{o[0], o[1], o[2], o[3]};
+            }
+        }
+    }
+}
+
+int launch_layernorm(int precision_out, const float* x, int ldx, int rows, int dim, const float* mul, const float* add, int mod_bstride,
+                     int rows_per_batch, int add_one, void* out, int ldo, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    if (dim % 4 != 0 || dim > 2048 || (ldx & 3) || (ldo & 3) || (mod_bstride & 3)) return f5_fail(F5_EINVAL, "layernorm: dim=%d unsupported", dim);
+    if (rows_per_batch <= 0) rows_per_batch = rows;
+    dim3 grid(cdiv(rows, 4)), block(256);
+    const float one = add_one ? 1.0f : 0.0f;
+    if (precision_out == F5_PREC_BF16) {
+        if (dim <= 1024)
+            hipLaunchKernelGGL((layernorm_kernel<bf16_t, 4>), grid, block, 0, stream, x, ldx, rows, dim, mul, add, mod_bstride, rows_per_batch, one, (bf16_t*)out, ldo);
+        else
+            hipLaunchKernelGGL((layernorm_kernel<bf16_t, 8>), grid, block, 0, stream, x, ldx, rows, dim, mul, add, mod_bstride, rows_per_batch, one, (bf16_t*)out, ldo);
+    } else {
+        if (dim <= 1024)
+            hipLaunchKernelGGL((layernorm_kernel<float, 4>), grid, block, 0, stream, x, ldx, rows, dim, mul, add, mod_bstride, rows_per_batch, one, (float*)out, ldo);
+        else
+            hipLaunchKernelGGL((layernorm_kernel<float, 8>), grid, block, 0, stream, x, ldx, rows, dim, mul, add, mod_bstride, rows_per_batch, one, (float*)out, ldo);
+    }
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+// ----------------------------------------------------------------------------- depthwise conv k=7 + LayerNorm(affine)
+template <typename TO, int MAXV>
+__global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict__ x, int B, int N, int C, const float* __restrict__ wt,
+                                                         const float* __restrict__ cbias, const float* __restrict__ ln_w,
+                                                         const float* __restrict__ ln_b, TO* __restrict__ out, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * N) return;
+    const int pos = row % N;
+    const int nvec = C >> 2;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+            f32x4 a = *reinterpret_cast<const f32x4*>(cbias + c * 4);
+#pragma unroll
+            for (int tap = 0; tap < 7; ++tap) {
+                const int sp = pos + tap - 3;
+                if (sp >= 0 && sp < N) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)(row + tap - 3) * C + c * 4);
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wt + (size_t)tap * C + c * 4);
+                    a += xv * wv;
+                }
+            }
+            v[i] = a;
+            s += (a[0] + a[1]) + (a[2] + a[3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + 1e-6f);
+    TO* orow = out + (size_t)row * ldo;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(ln_w + c * 4);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(ln_b + c * 4);
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * w4[e] + b4[e];
+            if constexpr (sizeof(TO) == 2) {
+                *reinterpret_cast<bf16x4*>(orow + c * 4) = bf16x4{(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+            } else {
+                *reinterpret_cast<f32x4*>(orow + c * 4) = f32x4{o[0], o[1], o[2], o[3]};
+            }
+        }
+    }
+}
+
+int launch_dwconv7_ln(int precision_out, const float* x, int B, int N, int C, const float* wt, const float* cbias, const float* ln_w,
+                      const float* ln_b, void* out, int ldo, hipStream_t stream) {
+    if (B * N <= 0) return 0;
+    if (C % 4 != 0 || C > 1024 || (ldo & 3)) return f5_fail(F5_EINVAL, "dwconv7_ln: C=%d unsupported", C);
+    dim3 grid(cdiv(B * N, 4)), block(256);
+    if (precision_out == F5_PREC_BF16)
+        hipLaunchKernelGGL((dwconv7_ln_kernel<bf16_t, 4>), grid, block, 0, stream, x, B, N, C, wt, cbias, ln_w, ln_b, (bf16_t*)out, ldo);
+    else
+        hipLaunchKernelGGL((dwconv7_ln_kernel<float, 4>), grid, block, 0, stream, x, B, N, C, wt, cbias, ln_w, ln_b, (float*)out, ldo);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+// ----------------------------------------------------------------------------- GRN
+// pass 1: sumsq[b][c] over the sequence; pass 2: Nx = G / (mean_c G + 1e-6); pass 3: apply in place.
+template <typename T>
+__global__ __launch_bounds__(256) void grn_sumsq_kernel(const T* __restrict__ h, int N, int C, float* __restrict__ sumsq) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < C)
+        for (int n = rg; n < N; n += 4) {
+            const float v = to_f32(h[((size_t)b * N + n) * C + c]);
+            s += v * v;
+        }
+    red[rg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rg == 0 && c < C) sumsq[(size_t)b * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void grn_norm_kernel(float* __restrict__ g, int C, float* __restrict__ meanbuf) {
+    // one block per batch element: g[b][c] = sqrt(sumsq); then divide by (mean_c + 1e-6)
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float v = sqrtf(g[(size_t)b * C + c]);
+        g[(size_t)b * C + c] = v;
+        s += v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float denom = ((red[0] + red[1]) + (red[2] + red[3])) / (float)C + 1e-6f;
+    if (threadIdx.x == 0) meanbuf[b] = denom;
+    for (int c = threadIdx.x; c < C; c += 256) g[(size_t)b * C + c] = g[(size_t)b * C + c] / denom;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void grn_apply_kernel(T* __restrict__ h, int N, int C, const float* __restrict__ nx, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const int b = (int)(i / ((size_t)N * C));
+    const float v = to_f32(h[i]);
+    h[i] = from_f32<T>(gamma[c] * (v * nx[(size_t)b * C + c]) + beta[c] + v);
+}
+
+int launch_grn(int precision, void* h, int B, int N, int C, const float* gamma, const float* beta, float* scratch, hipStream_t stream) {
+    if (B * N <= 0) return 0;
+    const size_t total = (size_t)B * N * C;
+    if (precision == F5_PREC_BF16)
+        hipLaunchKernelGGL((grn_sumsq_kernel<bf16_t>), dim3(cdiv(C, 64), B), dim3(256), 0, stream, (const bf16_t*)h, N, C, scratch);
+    else
+        hipLaunchKernelGGL((grn_sumsq_kernel<float>), dim3(cdiv(C, 64), B), dim3(256), 0, stream, (const float*)h, N, C, scratch);
+    F5_LAUNCH_CHECK();
+    hipLaunchKernelGGL(grn_norm_kernel, dim3(B), dim3(256), 0, stream, scratch, C, scratch + (size_t)B * C);
+    F5_LAUNCH_CHECK();
+    if (precision == F5_PREC_BF16)
+        hipLaunchKernelGGL((grn_apply_kernel<bf16_t>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (bf16_t*)h, N, C, scratch, gamma, beta, total);
+    else
+        hipLaunchKernelGGL((grn_apply_kernel<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (float*)h, N, C, scratch, gamma, beta, total);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+// ----------------------------------------------------------------------------- text embedding gather (dit.py:49-68)
+__global__ __launch_bounds__(256) void text_gather_kernel(const int32_t* __restrict__ text, int nt, int B, int N, int td,
+                                                          const float* __restrict__ table, const float* __restrict__ pos_table, int drop_text,
+                                                          float* __restrict__ out, uint8_t* __restrict__ filler) {
+    const int row = blockIdx.x;  // b * N + p
+    const int b = row / N, p = row % N;
+    int tok = 0;
+    if (p < nt) tok = text[(size_t)b * nt + p] + 1;  // +1: 0 is the filler token; batch padding -1 -> 0
+    if (threadIdx.x == 0 && filler) filler[row] = tok == 0;
+    if (drop_text) tok = 0;
+    const int pp = p < 4096 ? p : 4095;  // get_pos_embed_indices clamps at precompute_max_pos (modules.py:218)
+    for (int c = threadIdx.x; c < td; c += 256) {
+        float v = table[(size_t)tok * td + c];
+        if (pos_table) v += pos_table[(size_t)pp * td + c];
+        out[(size_t)row * td + c] = v;
+    }
+}
+int launch_text_gather(const int32_t* text, int nt, int B, int N, int td, const float* table, const float* pos_table, int drop_text,
+                       float* out, uint8_t* filler, hipStream_t stream) {
+    if (B * N <= 0) return 0;
+    hipLaunchKernelGGL(text_gather_kernel, dim3(B * N), dim3(256), 0, stream, text, nt, B, N, td, table, pos_table, drop_text, out, filler);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void mask_rows_kernel(float* __restrict__ x, int rows, int cols, const uint8_t* __restrict__ flags) {
+    const int row = blockIdx.x;
+    if (!flags[row]) return;
+    for (int c = threadIdx.x; c < cols; c += 256) x[(size_t)row * cols + c] = 0.f;
+}
+int launch_mask_rows(float* x, int rows, int cols, const uint8_t* zero_flags, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(mask_rows_kernel, dim3(rows), dim3(256), 0, stream, x, rows, cols, zero_flags);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+// ----------------------------------------------------------------------------- timestep embedding (modules.py:149-161)
+__global__ void time_sinus_kernel(const float* __restrict__ t, int n, float* __restrict__ out) {
+    const int i = blockIdx.x, j = threadIdx.x;  // 128 threads
+    const float k = logf(10000.0f) / 127.0f;
+    const float f = expf((float)j * -k);
+    const float arg = 1000.0f * t[i] * f;
+    out[(size_t)i * 256 + j] = sinf(arg);
+    out[(size_t)i * 256 + 128 + j] = cosf(arg);
+}
+int launch_time_sinus(const float* t, int n, float* out, hipStream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(time_sinus_kernel, dim3(n), dim3(128), 0, stream, t, n, out);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+// ----------------------------------------------------------------------------- small-M fp32 linear (time MLP, AdaLN modulation)
+// one wavefront per output feature; the weight row stays in registers while the (few) input rows stream from L2.
+template <int KV>  // K <= KV * 256
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ in, int ldi, int rows, const float* __restrict__ W,
+                                                        const float* __restrict__ b, int N, int K, int pre_silu, int post_silu,
+                                                        float* __restrict__ out, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int nvec = K >> 2;
+    f32x4 w[KV];
+#pragma unroll
+    for (int i = 0; i < KV; ++i) {
+        const int c = lane + i * 64;
+        w[i] = c < nvec ? *reinterpret_cast<const f32x4*>(W + (size_t)n * K + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float bias = b ? b[n] : 0.f;
+    for (int r = 0; r < rows; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < KV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nvec) {
+                f32x4 x = *reinterpret_cast<const f32x4*>(in + (size_t)r * ldi + c * 4);
+                if (pre_silu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = act_silu(x[e]);
+                }
+                s += (x[0] * w[i][0] + x[1] * w[i][1]) + (x[2] * w[i][2] + x[3] * w[i][3]);
+            }
+        }
+        s = wave_sum(s) + bias;
+        if (post_silu) s = act_silu(s);
+        if (lane == 0) out[(size_t)r * ldo + n] = s;
+    }
+}
+int launch_gemv_rows(const float* in, int ldi, int rows, const float* W, const float* b, int N, int K, int pre_silu, int post_silu,
+                     float* out, int ldo, hipStream_t stream) {
+    if (rows <= 0 || N <= 0) return 0;
+    if (K % 4 != 0 || K > 2048 || (ldi & 3)) return f5_fail(F5_EINVAL, "gemv_rows: K=%d unsupported", K);
+    dim3 grid(cdiv(N, 4)), block(256);
+    if (K <= 256)
+        hipLaunchKernelGGL((gemv_rows_kernel<1>), grid, block, 0, stream, in, ldi, rows, W, b, N, K, pre_silu, post_silu, out, ldo);
+    else if (K <= 1024)
+        hipLaunchKernelGGL((gemv_rows_kernel<4>), grid, block, 0, stream, in, ldi, rows, W, b, N, K, pre_silu, post_silu, out, ldo);
+    else
+        hipLaunchKernelGGL((gemv_rows_kernel<8>), grid, block, 0, stream, in, ldi, rows, W, b, N, K, pre_silu, post_silu, out, ldo);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+// ----------------------------------------------------------------------------- conversions / packing
+template <typename TO>
+__global__ __launch_bounds__(256) void convert_pad_kernel(const float* __restrict__ src, int lds, int rows, int cols, int padcols, TO* __restrict__ dst, int ldo) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)rows * padcols) return;
+    const int r = (int)(i / padcols), c = (int)(i % padcols);
+    dst[(size_t)r * ldo + c] = from_f32<TO>(c < cols ? src[(size_t)r * lds + c] : 0.f);
+}
+int launch_convert_pad(int precision_out, const float* src, int lds, int rows, int cols, int padcols, void* dst, int ldo, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    const size_t total = (size_t)rows * padcols;
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (precision_out == F5_PREC_BF16)
+        hipLaunchKernelGGL((convert_pad_kernel<bf16_t>), grid, block, 0, stream, src, lds, rows, cols, padcols, (bf16_t*)dst, ldo);
+    else
+        hipLaunchKernelGGL((convert_pad_kernel<float>), grid, block, 0, stream, src, lds, rows, cols, padcols, (float*)dst, ldo);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+template <typename TI>
+__global__ __launch_bounds__(256) void convert_back_kernel(const TI* __restrict__ src, int lds, int rows, int cols, float* __restrict__ dst, int ldd) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    dst[(size_t)r * ldd + c] = to_f32(src[(size_t)r * lds + c]);
+}
+int launch_convert_back(int precision_in, const void* src, int lds, int rows, int cols, float* dst, int ldd, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    const size_t total = (size_t)rows * cols;
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (precision_in == F5_PREC_BF16)
+        hipLaunchKernelGGL((convert_back_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)src, lds, rows, cols, dst, ldd);
+    else
+        hipLaunchKernelGGL((convert_back_kernel<float>), grid, block, 0, stream, (const float*)src, lds, rows, cols, dst, ldd);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+// A_base row m = [ cond[m][0..mel) masked by lens | 0 pad to melp | text_embed[m][0..td) ]
+template <typename TO>
+__global__ __launch_bounds__(256) void pack_base_kernel(const float* __restrict__ cond, const int32_t* __restrict__ lens, const float* __restrict__ te,
+                                                        int B, int N, int mel, int melp, int td, int zero_cond, TO* __restrict__ dst, int ldd) {
+    const int row = blockIdx.x;
+    const int b = row / N, p = row % N;
+    const bool keep = !zero_cond && (lens == nullptr || p < lens[b]);  // step_cond = where(cond_mask, cond, 0) (cfm.py:148-150)
+    for (int c = threadIdx.x; c < melp + td; c += 256) {
+        float v;
+        if (c < melp)
+            v = (keep && c < mel) ? cond[(size_t)row * mel + c] : 0.f;
+        else
+            v = te[(size_t)row * td + (c - melp)];
+        dst[(size_t)row * ldd + c] = from_f32<TO>(v);
+    }
+}
+int launch_pack_base(int precision_out, const float* cond, const int32_t* lens, const float* text_embed, int B, int N, int mel, int melp,
+                     int td, int zero_cond, void* dst, int ldd, hipStream_t stream) {
+    if (B * N <= 0) return 0;
+    if (precision_out == F5_PREC_BF16)
+        hipLaunchKernelGGL((pack_base_kernel<bf16_t>), dim3(B * N), dim3(256), 0, stream, cond, lens, text_embed, B, N, mel, melp, td, zero_cond, (bf16_t*)dst, ldd);
+    else
+        hipLaunchKernelGGL((pack_base_kernel<float>), dim3(B * N), dim3(256), 0, stream, cond, lens, text_embed, B, N, mel, melp, td, zero_cond, (float*)dst, ldd);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+// ----------------------------------------------------------------------------- CFG combine + fixed-grid ODE step
+__global__ __launch_bounds__(256) void cfg_step_kernel(const float* __restrict__ x_base, const float* __restrict__ vc, const float* __restrict__ vu, int ldv,
+                                                       int rows, int mel, float cfg, const float* __restrict__ coef, float* __restrict__ x_out,
+                                                       float* __restrict__ x_out2) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)rows * mel) return;
+    const int r = (int)(i / mel), c = (int)(i % mel);
+    const float pc = vc[(size_t)r * ldv + c];
+    float f = pc;
+    if (vu) f = pc + (pc - vu[(size_t)r * ldv + c]) * cfg;  // pred + (pred - null_pred) * cfg_strength (cfm.py:173)
+    const float y = x_base[i] + coef[0] * f;
+    x_out[i] = y;
+    if (x_out2) x_out2[i] = y;
+}
+int launch_cfg_step(const float* x_base, const float* vc, const float* vu, int ldv, int rows, int mel, float cfg, const float* coef,
+                    float* x_out, float* x_out2, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    const size_t total = (size_t)rows * mel;
+    hipLaunchKernelGGL(cfg_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x_base, vc, vu, ldv, rows, mel, cfg, coef, x_out, x_out2);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void final_where_kernel(const float* __restrict__ cond, const float* __restrict__ x, const int32_t* __restrict__ lens,
+                                                          int B, int N, int mel, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * N * mel) return;
+    const int row = (int)(i / mel);
+    const int b = row / N, p = row % N;
+    out[i] = p < lens[b] ? cond[i] : x[i];
+}
+int launch_final_where(const float* cond, const float* x, const int32_t* lens, int B, int N, int mel, float* out, hipStream_t stream) {
+    const size_t total = (size_t)B * N * mel;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(final_where_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, cond, x, lens, B, N, mel, out);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void len_mask_kernel(const int32_t* __restrict__ durations, int B, int N, uint8_t* __restrict__ mask) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * N) return;
+    mask[i] = (i % N) < durations[i / N];
+}
+int launch_len_mask(const int32_t* durations, int B, int N, uint8_t* mask, hipStream_t stream) {
+    if (B * N <= 0) return 0;
+    hipLaunchKernelGGL(len_mask_kernel, dim3(cdiv(B * N, 256)), dim3(256), 0, stream, durations, B, N, mask);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ dst, size_t n, float v) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = v;
+}
+int launch_fill_f32(float* dst, size_t n, float v, hipStream_t stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dst, n, v);
+    F5_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,51 @@
+// gemm.h -- the dense contraction engine of libf5hip:  out[M,N] = epilogue(A[M,K] . W[N,K]^T)
+//
+// Both operands are K-contiguous (activations row-major, weights in PyTorch's [out, in] layout), which
+// is exactly the MFMA fragment order on CDNA4 (8 consecutive k per lane).  The MFMA is issued "swapped"
+// (weight rows on the MFMA row index, tokens on the lane/column index) so that every lane ends up with
+// 4 consecutive output features of one token: RoPE pairs are lane-local and stores are 8/16-byte vectors.
+#pragma once
+#include "common.h"
+
+enum GemmMode {
+    GEMM_DENSE = 0,  // plain A[M,K]
+    GEMM_CONV31 = 1  // grouped Conv1d(k=31, groups=dim/64, pad=15) as an implicit GEMM: K = 31 taps x 64 channels
+};
+
+enum GemmEpi {
+    EPI_STORE_T = 0,    // out_t[m][n]  = act(acc + bias[n])                                (activation dtype)
+    EPI_STORE_F32 = 1,  // out_f[m][n]  = act(acc + bias[n])                                (f32)
+    EPI_RESID = 2,      // out_f[m][n] += gate[b(m)][n] * act(acc + bias[n]), skipped where rowmask[m]==0
+    EPI_ADD2 = 3,       // v = acc + bias[n] + addend[m][n];  out_t[m][n] = v;  out_f[m][n] = v
+    EPI_ROPE_T = 4      // out_t = rope(acc + bias) on the q/k columns of the first pe heads (fused QKV projection)
+};
+
+struct GemmParams {
+    const void* A;  // [M(or a_row_mod), K] activation dtype
+    const void* W;  // DENSE: [N, K];  CONV31: [31][N][conv_win] (tap-major, zero outside the row's own group)
+    int lda, ldw;
+    int M, N, K;
+    int a_row_mod;  // > 0: A row = m % a_row_mod (both CFG branches read the same noisy mel rows)
+    const float* bias;  // [N] or null
+    int act;            // Act
+    void* out_t;        // activation dtype output
+    int ldo;
+    float* out_f;  // f32 output / residual stream (read-modify-write for EPI_RESID)
+    int ldof;
+    const float* addend;  // EPI_ADD2
+    int ldadd;
+    const float* gate;  // EPI_RESID: gate[b * gate_bstride + n] or null (=1)
+    int gate_bstride;
+    int rows_per_batch;      // sequence length N_seq: b(m) = m / rows_per_batch, position = m % rows_per_batch
+    const uint8_t* rowmask;  // [M] or null
+    const float* rope;       // [N_seq][32][2] (cos, sin)
+    int rope_inner;          // heads * 64
+    int rope_heads;          // heads that receive RoPE
+    // CONV31: channels per group (dim/16) and the padded input-channel window one 64-channel output tile reads
+    int conv_cg, conv_win;
+};
+
+// kernel_kind: 0 = reference tile kernel (any shape), 1 = tuned 256x256 LDS-DMA bf16 kernel
+int launch_gemm(const GemmParams& p, int precision, int mode, int epi, int kernel_kind, hipStream_t stream);
+// true when the tuned kernel can run this problem (bf16, tile-multiple shapes, supported epilogue)
+bool gemm_fast_supported(const GemmParams& p, int precision, int mode, int epi);

@@ -1,0 +1,53 @@
+// kernels.h -- launchers of the non-GEMM kernels (all enqueue on `stream`, never synchronise).
+#pragma once
+#include "common.h"
+
+// ---- attention.hip
+// qkv: [B*N, 3*H*64] (q | k | v, token-major), mask u8 [B, N] or null, out [B*N, H*64]; activation dtype by precision.
+// kernel_kind 0: reference kernel (fp32 VALU math, any N); 1: tuned bf16 flash kernel (MFMA, in-register softmax).
+int launch_attention(int precision, int kernel_kind, int B, int N, int H, const void* qkv, int ldq, const uint8_t* mask, void* out,
+                     int ldo, hipStream_t stream);
+bool attention_fast_supported(int precision, int N, int H);
+
+// ---- elementwise.hip
+// out[r][c] = LN(x[r][:])[c] * (add_one + mul[b(r)][c]) + add[b(r)][c]; b(r) = r / rows_per_batch; eps 1e-6
+int launch_layernorm(int precision_out /*F5_PREC_* of `out`*/, const float* x, int ldx, int rows, int dim, const float* mul,
+                     const float* add, int mod_bstride, int rows_per_batch, int add_one, void* out, int ldo, hipStream_t stream);
+// depthwise Conv1d(k=7, pad=3) along the sequence (+bias) then LayerNorm(eps 1e-6, affine) -> activation dtype
+// x f32 [B*N, C]; wt f32 [7][C] (tap-major); out [B*N, C]
+int launch_dwconv7_ln(int precision_out, const float* x, int B, int N, int C, const float* wt, const float* cbias, const float* ln_w,
+                      const float* ln_b, void* out, int ldo, hipStream_t stream);
+// GRN (modules.py:225-234) in place on h [B*N, C] (activation dtype): h = gamma * (h * Nx) + beta + h
+int launch_grn(int precision, void* h, int B, int N, int C, const float* gamma, const float* beta, float* scratch /*[B*C + B]*/,
+               hipStream_t stream);
+// text ids -> embedding rows (+ abs-pos table) ; also writes filler flags [B*N] (1 where the id is the filler 0)
+int launch_text_gather(const int32_t* text, int nt, int B, int N, int td, const float* table, const float* pos_table /*or null*/,
+                       int drop_text, float* out, uint8_t* filler, hipStream_t stream);
+int launch_mask_rows(float* x, int rows, int cols, const uint8_t* zero_flags, hipStream_t stream);
+// sinusoidal timestep embedding (modules.py:149-161): t [n] -> out [n, 256]
+int launch_time_sinus(const float* t, int n, float* out, hipStream_t stream);
+// small-M fp32 linear: out[r][n] = post( sum_k pre(in[r][k]) * W[n][k] + b[n] ), pre/post in {none, silu}
+int launch_gemv_rows(const float* in, int ldi, int rows, const float* W, const float* b, int N, int K, int pre_silu, int post_silu,
+                     float* out, int ldo, hipStream_t stream);
+// f32 [rows, cols] -> activation dtype [rows, ldo] with zero padding of columns cols..padcols-1
+int launch_convert_pad(int precision_out, const float* src, int lds, int rows, int cols, int padcols, void* dst, int ldo, hipStream_t stream);
+int launch_convert_back(int precision_in, const void* src, int lds, int rows, int cols, float* dst, int ldd, hipStream_t stream);
+// A_base rows: [cond(mel, padded to melp) | text_embed(td)] per branch (see model.cpp)
+int launch_pack_base(int precision_out, const float* cond, const int32_t* lens, const float* text_embed, int B, int N, int mel, int melp,
+                     int td, int zero_cond, void* dst, int ldd, hipStream_t stream);
+// x_out = x_base + coef[0] * (vc + (vc - vu) * cfg)   (cfm.py:173 + torchdiffeq step); vu == null -> x_base + coef * vc
+int launch_cfg_step(const float* x_base, const float* vc, const float* vu, int ldv, int rows, int mel, float cfg, const float* coef,
+                    float* x_out, float* x_out2 /*or null*/, hipStream_t stream);
+// out = frame < lens[b] ? cond : x   (cfm.py:200-202)
+int launch_final_where(const float* cond, const float* x, const int32_t* lens, int B, int N, int mel, float* out, hipStream_t stream);
+// mask[b][n] = n < durations[b]
+int launch_len_mask(const int32_t* durations, int B, int N, uint8_t* mask, hipStream_t stream);
+int launch_fill_f32(float* dst, size_t n, float v, hipStream_t stream);
+
+// ---- vocos.hip
+// im2col for Conv1d(k=7, pad=3): mel f32 [B, C, T] -> rows [B*T, Kp] (col = tap*C + c, zero padded to Kp)
+int launch_vocos_im2col(int precision_out, const float* mel, int B, int C, int T, void* dst, int Kp, hipStream_t stream);
+// head.out activations [B*T, ld] (log-mag | phase) -> spectrum rows [B*T, Kp]: (re_0..re_{F-1}, im_0..im_{F-1}), F = n_fft/2+1
+int launch_vocos_spectrum(int precision_out, const float* head, int ldh, int rows, int F, void* dst, int Kp, hipStream_t stream);
+// overlap-add of windowed frames [B*T, n_fft] (hop), divide by the window-square envelope, trim n_fft/2 each side
+int launch_vocos_ola(const float* frames, int B, int T, int n_fft, int hop, const float* wsq /*[n_fft]*/, float* wave, hipStream_t stream);

@@ -1,0 +1,730 @@
+// model.hip -- DiT weights in HBM, the per-(batch, seq) plan/workspace, DiT.forward, CFM.sample and hipGraph replay.
+//
+// Reference semantics followed (paths under /root/reference/src/f5_tts):
+//   model/backbones/dit.py:185-233  DiT.forward          model/cfm.py:82-208   CFM.sample
+//   model/modules.py:301-336,610-641 AdaLN / DiTBlock     torchdiffeq fixed-grid euler / midpoint
+//
+// MI355X-first restructuring (algebraically identical):
+//   * time is one scalar per evaluation, so every AdaLN modulation vector of every block is computed ONCE per
+//     sample() for all evaluation times (fp32 weights, small-M kernel) and never touches the ODE loop again;
+//   * the input projection is split: W_cond.cond + W_text.text_embed + b is constant over the ODE loop and is
+//     computed once per CFG branch; per step only W_x.x (K = 100 -> 128) is evaluated;
+//   * CFG runs cond and uncond branches as ONE 2B batch through every kernel;
+//   * the whole loop (precompute + steps x evaluation) is captured into one hipGraph per shape bucket.
+#include <cmath>
+#include <cstring>
+
+#include "gemm.h"
+#include "kernels.h"
+#include "runtime.h"
+
+static const int MELP = 128;  // mel channels padded to one MFMA k-block multiple
+
+struct BlockW {
+    void *w_qkv = nullptr, *w_o = nullptr, *w_ff1 = nullptr, *w_ff2 = nullptr;
+    float *b_qkv = nullptr, *b_o = nullptr, *b_ff1 = nullptr, *b_ff2 = nullptr;
+};
+struct TextBlockW {
+    float *dw_wt = nullptr, *dw_b = nullptr, *ln_w = nullptr, *ln_b = nullptr, *b1 = nullptr, *gamma = nullptr, *beta = nullptr, *b2 = nullptr;
+    void *w1 = nullptr, *w2 = nullptr;
+};
+
+struct f5_model_s {
+    f5_dit_config cfg;
+    SlotMap slots;
+    bool finalized = false;
+    DevArena arena;
+    int inner = 0, modrow = 0, conv_cg = 0, conv_win = 0, rope_heads = 0;
+    std::vector<BlockW> blocks;
+    std::vector<TextBlockW> tblocks;
+    float *w_adaln = nullptr, *b_adaln = nullptr;  // [depth*6D + 2D, D] fp32: every attn_norm.linear then norm_out.linear
+    float *w_t0 = nullptr, *b_t0 = nullptr, *w_t2 = nullptr, *b_t2 = nullptr;
+    float *text_table = nullptr, *text_pos = nullptr;
+    void *w_x = nullptr, *w_ct = nullptr;
+    float* b_in = nullptr;
+    void* w_conv[2] = {nullptr, nullptr};
+    float* b_conv[2] = {nullptr, nullptr};
+    void* w_out = nullptr;
+    float* b_out = nullptr;
+    float inv_freq[32];
+};
+
+struct GraphEntry {
+    int B, N, nt, steps, method, cfg_on, mask_on;
+    float cfg;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+struct f5_plan_s {
+    f5_model_s* m = nullptr;
+    int maxB = 0, maxN = 0, maxE = 0;
+    size_t rows_cap = 0;
+    DevArena arena;
+    float *xres = nullptr, *base = nullptr, *vout = nullptr, *mod = nullptr, *temb = nullptr, *tsin = nullptr, *thid = nullptr;
+    float *tvals = nullptr, *coefs = nullptr, *te[2] = {nullptr, nullptr}, *grn_scratch = nullptr, *traj = nullptr, *xmid = nullptr;
+    float *cond_in = nullptr, *rope = nullptr, *tap_scratch = nullptr;
+    void *hT = nullptr, *cT = nullptr, *qkv = nullptr, *ffh = nullptr, *abase = nullptr, *xin = nullptr, *teT = nullptr, *te_h = nullptr;
+    uint8_t *filler = nullptr, *mask = nullptr;
+    int32_t *text_in = nullptr, *lens_in = nullptr, *dur_in = nullptr;
+    int rope_n = 0;
+    int gemm_kernel = -1, attn_kernel = -1;  // -1 = auto (tuned kernel when it supports the problem)
+    std::map<std::string, float*> taps;
+    std::vector<GraphEntry> graphs;
+};
+
+// ----------------------------------------------------------------------------- model
+static void add_slot(SlotMap& s, const std::string& name, std::vector<int64_t> shape) { s[name].shape = std::move(shape); }
+
+extern "C" int f5_model_create(const f5_dit_config* c, f5_model_t* out) {
+    if (!c || !out) return f5_fail(F5_EINVAL, "null argument");
+    *out = nullptr;
+    F5_TRY(f5_check_device());
+    if (c->qk_norm) return f5_fail(F5_ENOTSUP, "qk_norm is not implemented (null in every shipped config)");
+    if (c->long_skip) return f5_fail(F5_ENOTSUP, "long_skip_connection is not implemented (False in every shipped config)");
+    if (c->dim_head != 64) return f5_fail(F5_ENOTSUP, "dim_head=%d: only 64 is implemented", c->dim_head);
+    if (c->dim <= 0 || c->dim % 128 != 0 || c->dim > 2048) return f5_fail(F5_EINVAL, "dim=%d must be a multiple of 128 (<= 2048)", c->dim);
+    if (c->depth <= 0 || c->heads <= 0 || c->ff_inner <= 0 || c->ff_inner % 32 != 0) return f5_fail(F5_EINVAL, "bad depth/heads/ff_inner");
+    if (c->mel_dim <= 0 || c->mel_dim > MELP || c->mel_dim % 4 != 0) return f5_fail(F5_EINVAL, "mel_dim=%d unsupported", c->mel_dim);
+    if (c->text_dim <= 0 || c->text_dim % 32 != 0 || c->text_dim > 1024) return f5_fail(F5_EINVAL, "text_dim=%d must be a multiple of 32", c->text_dim);
+    if (c->text_num_embeds <= 0 || c->conv_layers < 0) return f5_fail(F5_EINVAL, "bad text config");
+    if (c->precision != F5_PREC_BF16 && c->precision != F5_PREC_FP32) return f5_fail(F5_EINVAL, "bad precision");
+    f5_model_s* m = new f5_model_s();
+    m->cfg = *c;
+    const int64_t D = c->dim, td = c->text_dim, inner = (int64_t)c->heads * 64, ff = c->ff_inner, mel = c->mel_dim;
+    m->inner = (int)inner;
+    m->modrow = (int)(c->depth * 6 * D + 2 * D);
+    m->rope_heads = (c->pe_attn_head <= 0 || c->pe_attn_head > c->heads) ? c->heads : c->pe_attn_head;
+    SlotMap& s = m->slots;
+    add_slot(s, "time_embed.time_mlp.0.weight", {D, 256});
+    add_slot(s, "time_embed.time_mlp.0.bias", {D});
+    add_slot(s, "time_embed.time_mlp.2.weight", {D, D});
+    add_slot(s, "time_embed.time_mlp.2.bias", {D});
+    add_slot(s, "text_embed.text_embed.weight", {c->text_num_embeds + 1, td});
+    for (int i = 0; i < c->conv_layers; ++i) {
+        const std::string p = "text_embed.text_blocks." + std::to_string(i) + ".";
+        add_slot(s, p + "dwconv.weight", {td, 1, 7});
+        add_slot(s, p + "dwconv.bias", {td});
+        add_slot(s, p + "norm.weight", {td});
+        add_slot(s, p + "norm.bias", {td});
+        add_slot(s, p + "pwconv1.weight", {2 * td, td});
+        add_slot(s, p + "pwconv1.bias", {2 * td});
+        add_slot(s, p + "grn.gamma", {1, 1, 2 * td});
+        add_slot(s, p + "grn.beta", {1, 1, 2 * td});
+        add_slot(s, p + "pwconv2.weight", {td, 2 * td});
+        add_slot(s, p + "pwconv2.bias", {td});
+    }
+    add_slot(s, "input_embed.proj.weight", {D, 2 * mel + td});
+    add_slot(s, "input_embed.proj.bias", {D});
+    for (int i = 0; i < 4; i += 2) {
+        add_slot(s, "input_embed.conv_pos_embed.conv1d." + std::to_string(i) + ".weight", {D, D / 16, 31});
+        add_slot(s, "input_embed.conv_pos_embed.conv1d." + std::to_string(i) + ".bias", {D});
+    }
+    for (int i = 0; i < c->depth; ++i) {
+        const std::string p = "transformer_blocks." + std::to_string(i) + ".";
+        add_slot(s, p + "attn_norm.linear.weight", {6 * D, D});
+        add_slot(s, p + "attn_norm.linear.bias", {6 * D});
+        for (const char* nm : {"to_q", "to_k", "to_v"}) {
+            add_slot(s, p + "attn." + nm + ".weight", {inner, D});
+            add_slot(s, p + "attn." + nm + ".bias", {inner});
+        }
+        add_slot(s, p + "attn.to_out.0.weight", {D, inner});
+        add_slot(s, p + "attn.to_out.0.bias", {D});
+        add_slot(s, p + "ff.ff.0.0.weight", {ff, D});
+        add_slot(s, p + "ff.ff.0.0.bias", {ff});
+        add_slot(s, p + "ff.ff.2.weight", {D, ff});
+        add_slot(s, p + "ff.ff.2.bias", {D});
+    }
+    add_slot(s, "norm_out.linear.weight", {2 * D, D});
+    add_slot(s, "norm_out.linear.bias", {2 * D});
+    add_slot(s, "proj_out.weight", {mel, D});
+    add_slot(s, "proj_out.bias", {mel});
+    // x_transformers RotaryEmbedding(64).inv_freq (persistent buffer; optional in checkpoints)
+    for (int j = 0; j < 32; ++j) m->inv_freq[j] = 1.0f / powf(10000.0f, (float)(2 * j) / 64.0f);
+    *out = m;
+    return 0;
+}
+
+extern "C" int f5_model_has_tensor(f5_model_t m, const char* name, int64_t* numel) {
+    if (!m || !name) return 0;
+    if (strcmp(name, "rotary_embed.inv_freq") == 0) {
+        if (numel) *numel = 32;
+        return 1;
+    }
+    auto it = m->slots.find(name);
+    if (it == m->slots.end()) return 0;
+    if (numel) *numel = it->second.numel();
+    return 1;
+}
+
+extern "C" int f5_model_set_tensor(f5_model_t m, const char* name, const float* host, const int64_t* shape, int ndim) {
+    if (!m || !name || !host || !shape) return f5_fail(F5_EINVAL, "null argument");
+    if (m->finalized) return f5_fail(F5_ESTATE, "model already finalized");
+    if (strcmp(name, "rotary_embed.inv_freq") == 0) {
+        if (ndim != 1 || shape[0] != 32) return f5_fail(F5_EINVAL, "rotary_embed.inv_freq must have 32 elements");
+        memcpy(m->inv_freq, host, 32 * sizeof(float));
+        return 0;
+    }
+    return f5_slot_set(m->slots, name, host, shape, ndim);
+}
+
+static const std::vector<float>& H(f5_model_s* m, const std::string& name) { return m->slots[name].host; }
+
+extern "C" int f5_model_finalize(f5_model_t m) {
+    if (!m) return f5_fail(F5_EINVAL, "null model");
+    if (m->finalized) return 0;
+    F5_TRY(f5_check_device());
+    F5_TRY(f5_slots_all_set(m->slots));
+    const f5_dit_config& c = m->cfg;
+    const int P = c.precision;
+    const size_t D = c.dim, td = c.text_dim, inner = m->inner, ff = c.ff_inner, mel = c.mel_dim;
+    DevArena& A = m->arena;
+    // time MLP (fp32)
+    F5_TRY(f5_upload_f32(A, H(m, "time_embed.time_mlp.0.weight").data(), D * 256, &m->w_t0));
+    F5_TRY(f5_upload_f32(A, H(m, "time_embed.time_mlp.0.bias").data(), D, &m->b_t0));
+    F5_TRY(f5_upload_f32(A, H(m, "time_embed.time_mlp.2.weight").data(), D * D, &m->w_t2));
+    F5_TRY(f5_upload_f32(A, H(m, "time_embed.time_mlp.2.bias").data(), D, &m->b_t2));
+    // AdaLN linears of every block + the final one, concatenated (fp32)
+    {
+        std::vector<float> w((size_t)m->modrow * D), b(m->modrow);
+        for (int i = 0; i < c.depth; ++i) {
+            const std::string p = "transformer_blocks." + std::to_string(i) + ".attn_norm.linear.";
+            memcpy(&w[(size_t)i * 6 * D * D], H(m, p + "weight").data(), 6 * D * D * sizeof(float));
+            memcpy(&b[(size_t)i * 6 * D], H(m, p + "bias").data(), 6 * D * sizeof(float));
+        }
+        memcpy(&w[(size_t)c.depth * 6 * D * D], H(m, "norm_out.linear.weight").data(), 2 * D * D * sizeof(float));
+        memcpy(&b[(size_t)c.depth * 6 * D], H(m, "norm_out.linear.bias").data(), 2 * D * sizeof(float));
+        F5_TRY(f5_upload_f32(A, w.data(), w.size(), &m->w_adaln));
+        F5_TRY(f5_upload_f32(A, b.data(), b.size(), &m->b_adaln));
+    }
+    // text embedder
+    F5_TRY(f5_upload_f32(A, H(m, "text_embed.text_embed.weight").data(), (size_t)(c.text_num_embeds + 1) * td, &m->text_table));
+    if (c.conv_layers > 0) {
+        // precompute_freqs_cis(text_dim, 4096): [cos | sin], theta_j = 10000^(-2j/dim)  (modules.py:196-207)
+        std::vector<float> pos((size_t)4096 * td);
+        const int half = (int)td / 2;
+        for (int j = 0; j < half; ++j) {
+            const float inv = 1.0f / powf(10000.0f, (float)(2 * j) / (float)td);
+            for (int p = 0; p < 4096; ++p) {
+                const float ang = (float)p * inv;
+                pos[(size_t)p * td + j] = cosf(ang);
+                pos[(size_t)p * td + half + j] = sinf(ang);
+            }
+        }
+        F5_TRY(f5_upload_f32(A, pos.data(), pos.size(), &m->text_pos));
+    }
+    m->tblocks.resize(c.conv_layers);
+    for (int i = 0; i < c.conv_layers; ++i) {
+        const std::string p = "text_embed.text_blocks." + std::to_string(i) + ".";
+        TextBlockW& t = m->tblocks[i];
+        std::vector<float> wt(7 * td);
+        const std::vector<float>& dw = H(m, p + "dwconv.weight");  // [td, 1, 7] -> tap-major [7][td]
+        for (size_t ch = 0; ch < td; ++ch)
+            for (int tap = 0; tap < 7; ++tap) wt[(size_t)tap * td + ch] = dw[ch * 7 + tap];
+        F5_TRY(f5_upload_f32(A, wt.data(), wt.size(), &t.dw_wt));
+        F5_TRY(f5_upload_f32(A, H(m, p + "dwconv.bias").data(), td, &t.dw_b));
+        F5_TRY(f5_upload_f32(A, H(m, p + "norm.weight").data(), td, &t.ln_w));
+        F5_TRY(f5_upload_f32(A, H(m, p + "norm.bias").data(), td, &t.ln_b));
+        F5_TRY(f5_upload_t(A, P, H(m, p + "pwconv1.weight").data(), 2 * td * td, &t.w1));
+        F5_TRY(f5_upload_f32(A, H(m, p + "pwconv1.bias").data(), 2 * td, &t.b1));
+        F5_TRY(f5_upload_f32(A, H(m, p + "grn.gamma").data(), 2 * td, &t.gamma));
+        F5_TRY(f5_upload_f32(A, H(m, p + "grn.beta").data(), 2 * td, &t.beta));
+        F5_TRY(f5_upload_t(A, P, H(m, p + "pwconv2.weight").data(), 2 * td * td, &t.w2));
+        F5_TRY(f5_upload_f32(A, H(m, p + "pwconv2.bias").data(), td, &t.b2));
+    }
+    // input projection split: columns [x | cond | text]  (dit.py:88,95 concat order)
+    {
+        const std::vector<float>& w = H(m, "input_embed.proj.weight");
+        const size_t kin = 2 * mel + td, kct = MELP + td;
+        std::vector<float> wx(D * MELP, 0.f), wct(D * kct, 0.f);
+        for (size_t n = 0; n < D; ++n) {
+            for (size_t k = 0; k < mel; ++k) wx[n * MELP + k] = w[n * kin + k];
+            for (size_t k = 0; k < mel; ++k) wct[n * kct + k] = w[n * kin + mel + k];
+            for (size_t k = 0; k < td; ++k) wct[n * kct + MELP + k] = w[n * kin + 2 * mel + k];
+        }
+        F5_TRY(f5_upload_t(A, P, wx.data(), wx.size(), &m->w_x));
+        F5_TRY(f5_upload_t(A, P, wct.data(), wct.size(), &m->w_ct));
+        F5_TRY(f5_upload_f32(A, H(m, "input_embed.proj.bias").data(), D, &m->b_in));
+    }
+    // grouped conv (k=31, groups=16) -> tap-major [31][D][win], zero outside each output row's own group
+    {
+        const int cg = (int)D / 16;
+        int win = 0;
+        for (int n0 = 0; n0 < (int)D; n0 += 64) {
+            const int w0 = (n0 / cg) * cg, w1 = ((n0 + 63) / cg + 1) * cg;
+            win = std::max(win, w1 - w0);
+        }
+        win = (int)round_up(win, 64);
+        m->conv_cg = cg;
+        m->conv_win = win;
+        for (int li = 0; li < 2; ++li) {
+            const std::string p = "input_embed.conv_pos_embed.conv1d." + std::to_string(li * 2) + ".";
+            const std::vector<float>& w = H(m, p + "weight");  // [D, cg, 31]
+            std::vector<float> r((size_t)31 * D * win, 0.f);
+            for (int n = 0; n < (int)D; ++n) {
+                const int w0 = ((n / 64 * 64) / cg) * cg, g0 = (n / cg) * cg;
+                for (int ci = 0; ci < cg; ++ci) {
+                    const int j = g0 + ci - w0;  // position of this input channel inside the tile's window
+                    for (int tap = 0; tap < 31; ++tap) r[((size_t)tap * D + n) * win + j] = w[((size_t)n * cg + ci) * 31 + tap];
+                }
+            }
+            F5_TRY(f5_upload_t(A, P, r.data(), r.size(), &m->w_conv[li]));
+            F5_TRY(f5_upload_f32(A, H(m, p + "bias").data(), D, &m->b_conv[li]));
+        }
+    }
+    // transformer blocks: fused QKV weight [3*inner, D]
+    m->blocks.resize(c.depth);
+    for (int i = 0; i < c.depth; ++i) {
+        const std::string p = "transformer_blocks." + std::to_string(i) + ".";
+        BlockW& b = m->blocks[i];
+        std::vector<float> w(3 * inner * D), bias(3 * inner);
+        const char* nm[3] = {"to_q", "to_k", "to_v"};
+        for (int j = 0; j < 3; ++j) {
+            memcpy(&w[(size_t)j * inner * D], H(m, p + "attn." + nm[j] + ".weight").data(), inner * D * sizeof(float));
+            memcpy(&bias[(size_t)j * inner], H(m, p + "attn." + nm[j] + ".bias").data(), inner * sizeof(float));
+        }
+        F5_TRY(f5_upload_t(A, P, w.data(), w.size(), &b.w_qkv));
+        F5_TRY(f5_upload_f32(A, bias.data(), bias.size(), &b.b_qkv));
+        F5_TRY(f5_upload_t(A, P, H(m, p + "attn.to_out.0.weight").data(), D * inner, &b.w_o));
+        F5_TRY(f5_upload_f32(A, H(m, p + "attn.to_out.0.bias").data(), D, &b.b_o));
+        F5_TRY(f5_upload_t(A, P, H(m, p + "ff.ff.0.0.weight").data(), ff * D, &b.w_ff1));
+        F5_TRY(f5_upload_f32(A, H(m, p + "ff.ff.0.0.bias").data(), ff, &b.b_ff1));
+        F5_TRY(f5_upload_t(A, P, H(m, p + "ff.ff.2.weight").data(), D * ff, &b.w_ff2));
+        F5_TRY(f5_upload_f32(A, H(m, p + "ff.ff.2.bias").data(), D, &b.b_ff2));
+    }
+    {
+        // proj_out rows padded to MELP so the tuned kernel can run it too (rows >= mel are zero)
+        std::vector<float> w((size_t)MELP * D, 0.f), b(MELP, 0.f);
+        memcpy(w.data(), H(m, "proj_out.weight").data(), mel * D * sizeof(float));
+        memcpy(b.data(), H(m, "proj_out.bias").data(), mel * sizeof(float));
+        F5_TRY(f5_upload_t(A, P, w.data(), w.size(), &m->w_out));
+        F5_TRY(f5_upload_f32(A, b.data(), b.size(), &m->b_out));
+    }
+    for (auto& kv : m->slots) {  // host copies are no longer needed
+        kv.second.host.clear();
+        kv.second.host.shrink_to_fit();
+    }
+    F5_HIP(hipDeviceSynchronize());
+    m->finalized = true;
+    return 0;
+}
+
+extern "C" int f5_model_destroy(f5_model_t m) {
+    delete m;
+    return 0;
+}
+
+// ----------------------------------------------------------------------------- plan
+extern "C" int f5_plan_create(f5_model_t m, int max_batch, int max_seq, int max_evals, f5_plan_t* out) {
+    if (!m || !out) return f5_fail(F5_EINVAL, "null argument");
+    *out = nullptr;
+    if (!m->finalized) return f5_fail(F5_ESTATE, "f5_model_finalize must be called before f5_plan_create");
+    if (max_batch <= 0 || max_seq <= 0 || max_evals <= 0 || max_seq > 4096) return f5_fail(F5_EINVAL, "bad plan sizes (seq <= 4096: cfm.py:93)");
+    F5_TRY(f5_check_device());
+    const f5_dit_config& c = m->cfg;
+    const size_t es = f5_elem_size(c.precision);
+    const size_t D = c.dim, td = c.text_dim, inner = m->inner, ff = c.ff_inner, mel = c.mel_dim;
+    f5_plan_s* p = new f5_plan_s();
+    p->m = m;
+    p->maxB = max_batch;
+    p->maxN = max_seq;
+    p->maxE = max_evals;
+    const size_t bn = (size_t)max_batch * max_seq;
+    const size_t rows = (size_t)round_up(2 * bn, 256);  // CFG-doubled, padded to the tuned GEMM's tile height
+    p->rows_cap = rows;
+    DevArena& A = p->arena;
+    const size_t modrows = std::max<size_t>(max_evals, 2 * (size_t)max_batch);
+    int rc = 0;
+    do {
+        if ((rc = A.alloc_t(&p->xres, rows * D))) break;
+        if ((rc = A.alloc_t(&p->base, rows * D))) break;
+        if ((rc = A.alloc_t(&p->vout, rows * MELP))) break;
+        if ((rc = A.alloc(&p->hT, rows * D * es))) break;
+        if ((rc = A.alloc(&p->cT, rows * std::max(D, inner) * es))) break;
+        if ((rc = A.alloc(&p->qkv, rows * 3 * inner * es))) break;
+        if ((rc = A.alloc(&p->ffh, rows * ff * es))) break;
+        if ((rc = A.alloc(&p->abase, rows * (MELP + td) * es))) break;
+        if ((rc = A.alloc(&p->xin, (size_t)round_up(bn, 256) * MELP * es))) break;
+        if ((rc = A.alloc_t(&p->mod, modrows * m->modrow))) break;
+        if ((rc = A.alloc_t(&p->temb, modrows * D))) break;
+        if ((rc = A.alloc_t(&p->thid, modrows * D))) break;
+        if ((rc = A.alloc_t(&p->tsin, modrows * 256))) break;
+        if ((rc = A.alloc_t(&p->tvals, modrows))) break;
+        if ((rc = A.alloc_t(&p->coefs, modrows))) break;
+        if ((rc = A.alloc_t(&p->te[0], bn * td))) break;
+        if ((rc = A.alloc_t(&p->te[1], bn * td))) break;
+        if ((rc = A.alloc(&p->teT, (size_t)round_up(bn, 256) * td * es))) break;
+        if ((rc = A.alloc(&p->te_h, (size_t)round_up(bn, 256) * 2 * td * es))) break;
+        if ((rc = A.alloc_t(&p->grn_scratch, (size_t)max_batch * 2 * td + max_batch))) break;
+        if ((rc = A.alloc_t(&p->filler, bn))) break;
+        if ((rc = A.alloc_t(&p->mask, 2 * bn))) break;
+        if ((rc = A.alloc_t(&p->traj, (size_t)(max_evals + 1) * bn * mel))) break;
+        if ((rc = A.alloc_t(&p->xmid, bn * mel))) break;
+        if ((rc = A.alloc_t(&p->cond_in, bn * mel))) break;
+        if ((rc = A.alloc_t(&p->text_in, bn))) break;
+        if ((rc = A.alloc_t(&p->lens_in, (size_t)max_batch))) break;
+        if ((rc = A.alloc_t(&p->dur_in, (size_t)max_batch))) break;
+        // RoPE table for positions < max_seq: angle = p * inv_freq_j in fp32, as x_transformers computes it
+        std::vector<float> rope((size_t)max_seq * 64);
+        for (int pos = 0; pos < max_seq; ++pos)
+            for (int j = 0; j < 32; ++j) {
+                const float ang = (float)pos * m->inv_freq[j];
+                rope[((size_t)pos * 32 + j) * 2] = cosf(ang);
+                rope[((size_t)pos * 32 + j) * 2 + 1] = sinf(ang);
+            }
+        if ((rc = f5_upload_f32(A, rope.data(), rope.size(), &p->rope))) break;
+        p->rope_n = max_seq;
+    } while (0);
+    if (rc) {
+        delete p;
+        return rc;
+    }
+    if (const char* e = getenv("F5HIP_GEMM_KERNEL")) p->gemm_kernel = atoi(e);
+    if (const char* e = getenv("F5HIP_ATTN_KERNEL")) p->attn_kernel = atoi(e);
+    *out = p;
+    return 0;
+}
+
+extern "C" int f5_plan_destroy(f5_plan_t p) {
+    if (!p) return 0;
+    for (auto& g : p->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    delete p;
+    return 0;
+}
+extern "C" int64_t f5_plan_workspace_bytes(f5_plan_t p) { return p ? (int64_t)p->arena.total : 0; }
+
+extern "C" int f5_plan_set_option(f5_plan_t p, const char* key, int value) {
+    if (!p || !key) return f5_fail(F5_EINVAL, "null argument");
+    if (strcmp(key, "gemm_kernel") == 0)
+        p->gemm_kernel = value;
+    else if (strcmp(key, "attn_kernel") == 0)
+        p->attn_kernel = value;
+    else
+        return f5_fail(F5_EINVAL, "unknown option '%s'", key);
+    for (auto& g : p->graphs) {  // captured graphs baked the previous choice
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    p->graphs.clear();
+    return 0;
+}
+
+extern "C" int f5_plan_set_tap(f5_plan_t p, const char* stage, float* dst) {
+    if (!p) return f5_fail(F5_EINVAL, "null plan");
+    if (!stage || !dst) {
+        p->taps.clear();
+        return 0;
+    }
+    p->taps[stage] = dst;
+    return 0;
+}
+
+// ----------------------------------------------------------------------------- helpers
+static GemmParams gp_zero() {
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    return g;
+}
+static int run_gemm(f5_plan_s* p, const GemmParams& g, int mode, int epi, hipStream_t st) {
+    const int prec = p->m->cfg.precision;
+    int kind = 0;
+    if (p->gemm_kernel != 0 && gemm_fast_supported(g, prec, mode, epi)) kind = 1;
+    return launch_gemm(g, prec, mode, epi, kind, st);
+}
+static float* tap_dst(f5_plan_s* p, const std::string& name) {
+    auto it = p->taps.find(name);
+    return it == p->taps.end() ? nullptr : it->second;
+}
+static int tap_f32(f5_plan_s* p, const std::string& name, const float* src, int ld, int rows, int cols, hipStream_t st) {
+    float* d = tap_dst(p, name);
+    if (!d) return 0;
+    return launch_convert_back(F5_PREC_FP32, src, ld, rows, cols, d, cols, st);
+}
+static int tap_t(f5_plan_s* p, const std::string& name, const void* src, int ld, int rows, int cols, hipStream_t st) {
+    float* d = tap_dst(p, name);
+    if (!d) return 0;
+    return launch_convert_back(p->m->cfg.precision, src, ld, rows, cols, d, cols, st);
+}
+
+// time values (device, n of them) -> modulation rows [n][modrow] (AdaLN of every block + final), t_emb in p->temb
+static int compute_modulation(f5_plan_s* p, const float* tvals_dev, int n, hipStream_t st) {
+    f5_model_s* m = p->m;
+    const int D = m->cfg.dim;
+    F5_TRY(launch_time_sinus(tvals_dev, n, p->tsin, st));
+    F5_TRY(launch_gemv_rows(p->tsin, 256, n, m->w_t0, m->b_t0, D, 256, 0, 1, p->thid, D, st));  // Linear -> SiLU
+    F5_TRY(launch_gemv_rows(p->thid, D, n, m->w_t2, m->b_t2, D, D, 0, 0, p->temb, D, st));      // Linear
+    F5_TRY(tap_f32(p, "t_emb", p->temb, D, n, D, st));
+    // every AdaLN: Linear(SiLU(t_emb))  (modules.py:311,332)
+    F5_TRY(launch_gemv_rows(p->temb, D, n, m->w_adaln, m->b_adaln, m->modrow, D, 1, 0, p->mod, m->modrow, st));
+    return 0;
+}
+
+// TextEmbedding.forward (dit.py:49-79) -> out f32 [B*N, td]
+static int compute_text_embed(f5_plan_s* p, const int32_t* text, int nt, int B, int N, int drop_text, float* out, hipStream_t st) {
+    f5_model_s* m = p->m;
+    const f5_dit_config& c = m->cfg;
+    const int td = c.text_dim, P = c.precision, rows = B * N;
+    const bool extra = c.conv_layers > 0;
+    F5_TRY(launch_text_gather(text, nt, B, N, td, m->text_table, extra ? m->text_pos : nullptr, drop_text, out, p->filler, st));
+    if (!extra) return 0;
+    const bool mp = c.text_mask_padding != 0;
+    if (mp) F5_TRY(launch_mask_rows(out, rows, td, p->filler, st));
+    for (int i = 0; i < c.conv_layers; ++i) {
+        const TextBlockW& t = m->tblocks[i];
+        F5_TRY(launch_dwconv7_ln(P, out, B, N, td, t.dw_wt, t.dw_b, t.ln_w, t.ln_b, p->teT, td, st));
+        GemmParams g = gp_zero();
+        g.A = p->teT; g.lda = td; g.W = t.w1; g.ldw = td; g.M = rows; g.N = 2 * td; g.K = td;
+        g.bias = t.b1; g.act = ACT_GELU_ERF; g.out_t = p->te_h; g.ldo = 2 * td;
+        F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_STORE_T, st));
+        F5_TRY(launch_grn(P, p->te_h, B, N, 2 * td, t.gamma, t.beta, p->grn_scratch, st));
+        g = gp_zero();
+        g.A = p->te_h; g.lda = 2 * td; g.W = t.w2; g.ldw = 2 * td; g.M = rows; g.N = td; g.K = 2 * td;
+        g.bias = t.b2; g.act = ACT_NONE; g.out_f = out; g.ldof = td; g.rows_per_batch = N;
+        F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_RESID, st));
+        if (mp) F5_TRY(launch_mask_rows(out, rows, td, p->filler, st));
+    }
+    return 0;
+}
+
+// base[rows, D] = b_in + W_cond . cond + W_text . text_embed for `nb` batch rows starting at row offset row0
+static int compute_base(f5_plan_s* p, const float* cond, const int32_t* lens, const float* te, int nb, int N, int zero_cond, size_t row0,
+                        hipStream_t st) {
+    f5_model_s* m = p->m;
+    const f5_dit_config& c = m->cfg;
+    const int D = c.dim, td = c.text_dim, P = c.precision, kct = MELP + td;
+    const size_t es = f5_elem_size(P);
+    void* ab = (char*)p->abase + row0 * kct * es;
+    F5_TRY(launch_pack_base(P, cond, lens, te, nb, N, c.mel_dim, MELP, td, zero_cond, ab, kct, st));
+    GemmParams g = gp_zero();
+    g.A = ab; g.lda = kct; g.W = m->w_ct; g.ldw = kct; g.M = nb * N; g.N = D; g.K = kct;
+    g.bias = m->b_in; g.out_f = p->base + row0 * D; g.ldof = D;
+    return run_gemm(p, g, GEMM_DENSE, EPI_STORE_F32, st);
+}
+
+// one network evaluation over `nb` batch rows (rows = nb*N) whose noisy mel rows are x[xrows, mel] (xrows divides rows);
+// modulation row for batch b is modp + b * mod_bstride.  Result: p->vout [rows, MELP] f32.
+static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, const float* modp, int mod_bstride, const uint8_t* mask,
+                    hipStream_t st) {
+    f5_model_s* m = p->m;
+    const f5_dit_config& c = m->cfg;
+    const int D = c.dim, P = c.precision, inner = m->inner, ff = c.ff_inner, rows = nb * N;
+    // input embedding: h = W_x . x + base ; x_res = h + mish(conv(mish(conv(h))))
+    F5_TRY(launch_convert_pad(P, x, c.mel_dim, xrows, c.mel_dim, MELP, p->xin, MELP, st));
+    GemmParams g = gp_zero();
+    g.A = p->xin; g.lda = MELP; g.W = m->w_x; g.ldw = MELP; g.M = rows; g.N = D; g.K = MELP;
+    g.a_row_mod = xrows < rows ? xrows : 0;
+    g.addend = p->base; g.ldadd = D; g.out_t = p->hT; g.ldo = D; g.out_f = p->xres; g.ldof = D;
+    F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_ADD2, st));
+    for (int li = 0; li < 2; ++li) {
+        g = gp_zero();
+        g.A = li == 0 ? p->hT : p->cT; g.lda = D; g.W = m->w_conv[li]; g.M = rows; g.N = D; g.K = 31 * m->conv_win;
+        g.bias = m->b_conv[li]; g.act = ACT_MISH; g.rows_per_batch = N; g.conv_cg = m->conv_cg; g.conv_win = m->conv_win;
+        if (li == 0) {
+            g.out_t = p->cT; g.ldo = D;
+            F5_TRY(run_gemm(p, g, GEMM_CONV31, EPI_STORE_T, st));
+        } else {
+            g.out_f = p->xres; g.ldof = D;
+            F5_TRY(run_gemm(p, g, GEMM_CONV31, EPI_RESID, st));
+        }
+    }
+    F5_TRY(tap_f32(p, "input_embed", p->xres, D, rows, D, st));
+
+    for (int l = 0; l < c.depth; ++l) {
+        const BlockW& b = m->blocks[l];
+        const float* ml = modp + (size_t)l * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp (modules.py:312)
+        const std::string tn = "blk" + std::to_string(l);
+        F5_TRY(launch_layernorm(P, p->xres, D, rows, D, ml + D, ml, mod_bstride, N, 1, p->hT, D, st));
+        F5_TRY(tap_t(p, tn + ".n1", p->hT, D, rows, D, st));
+        g = gp_zero();
+        g.A = p->hT; g.lda = D; g.W = b.w_qkv; g.ldw = D; g.M = rows; g.N = 3 * inner; g.K = D;
+        g.bias = b.b_qkv; g.out_t = p->qkv; g.ldo = 3 * inner; g.rows_per_batch = N;
+        g.rope = p->rope; g.rope_inner = inner; g.rope_heads = m->rope_heads;
+        F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_ROPE_T, st));
+        {
+            int kind = 0;
+            if (p->attn_kernel != 0 && attention_fast_supported(P, N, c.heads)) kind = 1;
+            F5_TRY(launch_attention(P, kind, nb, N, c.heads, p->qkv, 3 * inner, mask, p->cT, inner, st));
+        }
+        if (float* d = tap_dst(p, tn + ".attn")) {  // Attention module output before gating (extra GEMM, debug only)
+            g = gp_zero();
+            g.A = p->cT; g.lda = inner; g.W = b.w_o; g.ldw = inner; g.M = rows; g.N = D; g.K = inner;
+            g.bias = b.b_o; g.out_f = d; g.ldof = D;
+            F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_STORE_F32, st));
+        }
+        g = gp_zero();
+        g.A = p->cT; g.lda = inner; g.W = b.w_o; g.ldw = inner; g.M = rows; g.N = D; g.K = inner;
+        g.bias = b.b_o; g.out_f = p->xres; g.ldof = D; g.gate = ml + 2 * D; g.gate_bstride = mod_bstride; g.rows_per_batch = N;
+        g.rowmask = mask;
+        F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_RESID, st));
+        F5_TRY(launch_layernorm(P, p->xres, D, rows, D, ml + 4 * D, ml + 3 * D, mod_bstride, N, 1, p->hT, D, st));
+        g = gp_zero();
+        g.A = p->hT; g.lda = D; g.W = b.w_ff1; g.ldw = D; g.M = rows; g.N = ff; g.K = D;
+        g.bias = b.b_ff1; g.act = ACT_GELU_TANH; g.out_t = p->ffh; g.ldo = ff;
+        F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_STORE_T, st));
+        g = gp_zero();
+        g.A = p->ffh; g.lda = ff; g.W = b.w_ff2; g.ldw = ff; g.M = rows; g.N = D; g.K = ff;
+        g.bias = b.b_ff2; g.out_f = p->xres; g.ldof = D; g.gate = ml + 5 * D; g.gate_bstride = mod_bstride; g.rows_per_batch = N;
+        F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_RESID, st));
+        F5_TRY(tap_f32(p, tn + ".out", p->xres, D, rows, D, st));
+    }
+    const float* mf = modp + (size_t)c.depth * 6 * D;  // final AdaLN: (scale, shift) (modules.py:333)
+    F5_TRY(launch_layernorm(P, p->xres, D, rows, D, mf, mf + D, mod_bstride, N, 1, p->hT, D, st));
+    F5_TRY(tap_t(p, "final_norm", p->hT, D, rows, D, st));
+    g = gp_zero();
+    g.A = p->hT; g.lda = D; g.W = m->w_out; g.ldw = D; g.M = rows; g.N = MELP; g.K = D;
+    g.bias = m->b_out; g.out_f = p->vout; g.ldof = MELP;
+    return run_gemm(p, g, GEMM_DENSE, EPI_STORE_F32, st);
+}
+
+static int check_plan_shape(f5_plan_s* p, int B, int N) {
+    if (!p) return f5_fail(F5_EINVAL, "null plan");
+    if (B <= 0 || N <= 0 || B > p->maxB || N > p->maxN || (size_t)B * N > (size_t)p->maxB * p->maxN)
+        return f5_fail(F5_EINVAL, "shape (B=%d, N=%d) exceeds the plan (B<=%d, N<=%d)", B, N, p->maxB, p->maxN);
+    return f5_check_device();
+}
+
+// ----------------------------------------------------------------------------- public: text embed / forward
+extern "C" int f5_text_embed(f5_plan_t p, int B, int N, const int32_t* text, int nt, int drop_text, float* out, f5_stream_t stream) {
+    F5_TRY(check_plan_shape(p, B, N));
+    if (!text || !out || nt <= 0) return f5_fail(F5_EINVAL, "null/empty text");
+    return compute_text_embed(p, text, nt, B, N, drop_text, out, (hipStream_t)stream);
+}
+
+extern "C" int f5_dit_forward(f5_plan_t p, int B, int N, const float* x, const float* cond, const float* text_embed, const float* time,
+                              int drop_audio_cond, const uint8_t* mask, float* out, f5_stream_t stream) {
+    F5_TRY(check_plan_shape(p, B, N));
+    if (!x || !cond || !text_embed || !time || !out) return f5_fail(F5_EINVAL, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    f5_model_s* m = p->m;
+    F5_TRY(compute_modulation(p, time, B, st));
+    F5_TRY(compute_base(p, cond, nullptr, text_embed, B, N, drop_audio_cond, 0, st));
+    F5_TRY(dit_eval(p, x, B * N, B, N, p->mod, m->modrow, mask, st));
+    return launch_convert_back(F5_PREC_FP32, p->vout, MELP, B * N, m->cfg.mel_dim, out, m->cfg.mel_dim, st);
+}
+
+// ----------------------------------------------------------------------------- public: sample
+struct SampleArgs {
+    int B, N, nt, steps, method, cfg_on, mask_on;
+    float cfg;
+};
+
+// everything between the staged inputs and the final state traj[steps]; capturable (no syncs, no allocations)
+static int sample_body(f5_plan_s* p, const SampleArgs& a, hipStream_t st) {
+    f5_model_s* m = p->m;
+    const f5_dit_config& c = m->cfg;
+    const int B = a.B, N = a.N, mel = c.mel_dim, bn = B * N;
+    const int nev = a.method == F5_ODE_MIDPOINT ? 2 * a.steps : a.steps;
+    const size_t state = (size_t)bn * mel;
+    F5_TRY(compute_modulation(p, p->tvals, nev, st));
+    // text embeddings are constants of the whole sample() (the reference caches them per branch, dit.py:202-210)
+    F5_TRY(compute_text_embed(p, p->text_in, a.nt, B, N, 0, p->te[0], st));
+    F5_TRY(compute_base(p, p->cond_in, p->lens_in, p->te[0], B, N, 0, 0, st));
+    if (a.cfg_on) {
+        F5_TRY(compute_text_embed(p, p->text_in, a.nt, B, N, 1, p->te[1], st));
+        F5_TRY(compute_base(p, p->cond_in, p->lens_in, p->te[1], B, N, 1, (size_t)bn, st));
+    }
+    const uint8_t* mask = nullptr;
+    if (a.mask_on) {
+        F5_TRY(launch_len_mask(p->dur_in, B, N, p->mask, st));
+        if (a.cfg_on) F5_HIP(hipMemcpyAsync(p->mask + bn, p->mask, bn, hipMemcpyDeviceToDevice, st));
+        mask = p->mask;
+    }
+    const int nb = a.cfg_on ? 2 * B : B;
+    for (int s = 0; s < a.steps; ++s) {
+        float* xs = p->traj + (size_t)s * state;
+        float* xn = p->traj + (size_t)(s + 1) * state;
+        const float* vu = a.cfg_on ? p->vout + (size_t)bn * MELP : nullptr;
+        if (a.method == F5_ODE_EULER) {
+            F5_TRY(dit_eval(p, xs, bn, nb, N, p->mod + (size_t)s * m->modrow, 0, mask, st));
+            F5_TRY(launch_cfg_step(xs, p->vout, vu, MELP, bn, mel, a.cfg, p->coefs + s, xn, nullptr, st));
+        } else {
+            F5_TRY(dit_eval(p, xs, bn, nb, N, p->mod + (size_t)(2 * s) * m->modrow, 0, mask, st));
+            F5_TRY(launch_cfg_step(xs, p->vout, vu, MELP, bn, mel, a.cfg, p->coefs + 2 * s, p->xmid, nullptr, st));
+            F5_TRY(dit_eval(p, p->xmid, bn, nb, N, p->mod + (size_t)(2 * s + 1) * m->modrow, 0, mask, st));
+            F5_TRY(launch_cfg_step(xs, p->vout, vu, MELP, bn, mel, a.cfg, p->coefs + 2 * s + 1, xn, nullptr, st));
+        }
+    }
+    return 0;
+}
+
+extern "C" int f5_sample(f5_plan_t p, int B, int N, const float* cond, const int32_t* text, int nt, const int32_t* lens,
+                         const int32_t* durations, const float* y0, const float* tgrid_host, int steps, float cfg_strength, int ode_method,
+                         float* out, float* trajectory, int use_graph, f5_stream_t stream) {
+    F5_TRY(check_plan_shape(p, B, N));
+    if (!cond || !text || !lens || !y0 || !tgrid_host || !out) return f5_fail(F5_EINVAL, "null argument");
+    if (steps <= 0 || nt <= 0) return f5_fail(F5_EINVAL, "steps and nt must be positive");
+    if (ode_method != F5_ODE_EULER && ode_method != F5_ODE_MIDPOINT) return f5_fail(F5_EINVAL, "bad ode_method");
+    const int nev = ode_method == F5_ODE_MIDPOINT ? 2 * steps : steps;
+    if (nev > p->maxE) return f5_fail(F5_EINVAL, "%d evaluations exceed the plan's max_evals=%d", nev, p->maxE);
+    hipStream_t st = (hipStream_t)stream;
+    f5_model_s* m = p->m;
+    const int mel = m->cfg.mel_dim, bn = B * N;
+    const size_t state = (size_t)bn * mel;
+    const int nt_eff = nt < N ? nt : N;  // tokens beyond the frame count are curtailed (dit.py:51)
+
+    // evaluation times / step coefficients, fp32 op order of torchdiffeq's fixed-grid solvers
+    std::vector<float> tv(nev), cf(nev);
+    for (int s = 0; s < steps; ++s) {
+        const float t0 = tgrid_host[s], t1 = tgrid_host[s + 1];
+        const float dt = t1 - t0;
+        if (ode_method == F5_ODE_EULER) {
+            tv[s] = t0;
+            cf[s] = dt;
+        } else {
+            const float half = 0.5f * dt;
+            tv[2 * s] = t0;
+            cf[2 * s] = half;
+            tv[2 * s + 1] = t0 + half;
+            cf[2 * s + 1] = dt;
+        }
+    }
+    // stage inputs into plan-owned buffers (graph nodes have fixed addresses)
+    F5_HIP(hipMemcpyAsync(p->tvals, tv.data(), nev * sizeof(float), hipMemcpyHostToDevice, st));
+    F5_HIP(hipMemcpyAsync(p->coefs, cf.data(), nev * sizeof(float), hipMemcpyHostToDevice, st));
+    F5_HIP(hipMemcpyAsync(p->cond_in, cond, state * sizeof(float), hipMemcpyDeviceToDevice, st));
+    F5_HIP(hipMemcpyAsync(p->traj, y0, state * sizeof(float), hipMemcpyDeviceToDevice, st));
+    F5_HIP(hipMemcpy2DAsync(p->text_in, (size_t)nt_eff * 4, text, (size_t)nt * 4, (size_t)nt_eff * 4, B, hipMemcpyDeviceToDevice, st));
+    F5_HIP(hipMemcpyAsync(p->lens_in, lens, B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    if (durations) F5_HIP(hipMemcpyAsync(p->dur_in, durations, B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+
+    SampleArgs a{B, N, nt_eff, steps, ode_method, cfg_strength >= 1e-5f ? 1 : 0, durations ? 1 : 0, cfg_strength};  // cfm.py:167
+    if (use_graph && p->taps.empty()) {
+        GraphEntry* ge = nullptr;
+        for (auto& g : p->graphs)
+            if (g.B == B && g.N == N && g.nt == a.nt && g.steps == steps && g.method == ode_method && g.cfg_on == a.cfg_on &&
+                g.mask_on == a.mask_on && g.cfg == a.cfg)
+                ge = &g;
+        if (!ge) {
+            GraphEntry g{B, N, a.nt, steps, ode_method, a.cfg_on, a.mask_on, a.cfg};
+            F5_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            int rc = sample_body(p, a, st);
+            hipError_t e = hipStreamEndCapture(st, &g.graph);
+            if (rc != 0) {
+                if (g.graph) (void)hipGraphDestroy(g.graph);
+                return rc;
+            }
+            if (e != hipSuccess) return f5_fail(F5_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+            e = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
+            if (e != hipSuccess) {
+                (void)hipGraphDestroy(g.graph);
+                return f5_fail(F5_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+            }
+            if (p->graphs.size() >= 8) {  // small LRU-less cache: drop the oldest bucket
+                (void)hipGraphExecDestroy(p->graphs[0].exec);
+                (void)hipGraphDestroy(p->graphs[0].graph);
+                p->graphs.erase(p->graphs.begin());
+            }
+            p->graphs.push_back(g);
+            ge = &p->graphs.back();
+        }
+        F5_HIP(hipGraphLaunch(ge->exec, st));
+    } else {
+        F5_TRY(sample_body(p, a, st));
+    }
+    F5_TRY(launch_final_where(p->cond_in, p->traj + (size_t)steps * state, p->lens_in, B, N, mel, out, st));
+    if (trajectory) F5_HIP(hipMemcpyAsync(trajectory, p->traj, (size_t)(steps + 1) * state * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+}

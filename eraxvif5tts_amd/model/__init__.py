@@ -1,0 +1,3 @@
+"""Same public names as ``f5_tts.model`` for the inference path (reference model/__init__.py:1-8)."""
+from .backbones.dit import DiT  # noqa: F401
+from .cfm import CFM  # noqa: F401

@@ -1,0 +1,235 @@
+"""DiT backbone (plug point A of the reference) executed by libf5hip on MI355X.
+
+Drop-in for ``f5_tts.model.backbones.dit.DiT`` (reference dit.py:103-233): same constructor kwargs, same
+``state_dict()`` names/shapes (so existing ``.pt`` / ``.safetensors`` checkpoints load with ``load_state_dict``),
+same ``forward(x, cond, text, time, drop_audio_cond, drop_text, mask=None, cache=False)``, ``clear_cache()`` and ``.dim``.
+
+The torch parameters are only the checkpoint-facing copy of the weights; all arithmetic happens in the HIP library
+(``include/f5hip.h``).  Nothing here computes the network in PyTorch: without the built library or without an MI355X
+``forward`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+
+import torch
+from torch import nn
+
+from .. import utils as _utils  # noqa: F401  (kept importable like the reference package layout)
+from ... import _lib
+
+
+def _param_spec(dim, depth, heads, dim_head, ff_inner, mel_dim, vocab, text_dim, conv_layers):
+    """(name, shape, init) for every tensor of the reference DiT.state_dict()."""
+    inner = heads * dim_head
+    spec = [("time_embed.time_mlp.0.weight", (dim, 256), "linear"), ("time_embed.time_mlp.0.bias", (dim,), ("bias", 256)),
+            ("time_embed.time_mlp.2.weight", (dim, dim), "linear"), ("time_embed.time_mlp.2.bias", (dim,), ("bias", dim)),
+            ("text_embed.text_embed.weight", (vocab + 1, text_dim), "normal")]
+    for i in range(conv_layers):
+        p = f"text_embed.text_blocks.{i}."
+        spec += [(p + "dwconv.weight", (text_dim, 1, 7), "linear"), (p + "dwconv.bias", (text_dim,), ("bias", 7)),
+                 (p + "norm.weight", (text_dim,), "ones"), (p + "norm.bias", (text_dim,), "zeros"),
+                 (p + "pwconv1.weight", (2 * text_dim, text_dim), "linear"), (p + "pwconv1.bias", (2 * text_dim,), ("bias", text_dim)),
+                 (p + "grn.gamma", (1, 1, 2 * text_dim), "zeros"), (p + "grn.beta", (1, 1, 2 * text_dim), "zeros"),
+                 (p + "pwconv2.weight", (text_dim, 2 * text_dim), "linear"), (p + "pwconv2.bias", (text_dim,), ("bias", 2 * text_dim))]
+    kin = 2 * mel_dim + text_dim
+    spec += [("input_embed.proj.weight", (dim, kin), "linear"), ("input_embed.proj.bias", (dim,), ("bias", kin))]
+    for i in (0, 2):
+        spec += [(f"input_embed.conv_pos_embed.conv1d.{i}.weight", (dim, dim // 16, 31), "linear"),
+                 (f"input_embed.conv_pos_embed.conv1d.{i}.bias", (dim,), ("bias", dim // 16 * 31))]
+    for i in range(depth):
+        p = f"transformer_blocks.{i}."
+        spec += [(p + "attn_norm.linear.weight", (6 * dim, dim), "zeros"), (p + "attn_norm.linear.bias", (6 * dim,), "zeros")]
+        for nm in ("to_q", "to_k", "to_v"):
+            spec += [(p + f"attn.{nm}.weight", (inner, dim), "linear"), (p + f"attn.{nm}.bias", (inner,), ("bias", dim))]
+        spec += [(p + "attn.to_out.0.weight", (dim, inner), "linear"), (p + "attn.to_out.0.bias", (dim,), ("bias", inner)),
+                 (p + "ff.ff.0.0.weight", (ff_inner, dim), "linear"), (p + "ff.ff.0.0.bias", (ff_inner,), ("bias", dim)),
+                 (p + "ff.ff.2.weight", (dim, ff_inner), "linear"), (p + "ff.ff.2.bias", (dim,), ("bias", ff_inner))]
+    # zero-initialised output path, as the reference's initialize_weights (dit.py:162-172)
+    spec += [("norm_out.linear.weight", (2 * dim, dim), "zeros"), ("norm_out.linear.bias", (2 * dim,), "zeros"),
+             ("proj_out.weight", (mel_dim, dim), "zeros"), ("proj_out.bias", (mel_dim,), "zeros")]
+    return spec
+
+
+def _register(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer=False):
+    mod = root
+    parts = dotted.split(".")
+    for part in parts[:-1]:
+        if part not in mod._modules:
+            mod.add_module(part, nn.Module())
+        mod = mod._modules[part]
+    if buffer:
+        mod.register_buffer(parts[-1], tensor)
+    else:
+        mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+
+class DiT(nn.Module):
+    def __init__(self, *, dim, depth=8, heads=8, dim_head=64, dropout=0.1, ff_mult=4, mel_dim=100, text_num_embeds=256,
+                 text_dim=None, text_mask_padding=True, qk_norm=None, conv_layers=0, pe_attn_head=None,
+                 long_skip_connection=False, checkpoint_activations=False, precision=None):
+        super().__init__()
+        if text_dim is None:
+            text_dim = mel_dim
+        if qk_norm is not None:
+            raise NotImplementedError("qk_norm is null in every shipped config and is not implemented by the HIP kernels")
+        if long_skip_connection:
+            raise NotImplementedError("long_skip_connection is False in every shipped config and is not implemented")
+        self.dim, self.depth, self.heads, self.dim_head = dim, depth, heads, dim_head
+        self.ff_inner = int(dim * ff_mult)
+        self.mel_dim, self.text_num_embeds, self.text_dim = mel_dim, text_num_embeds, text_dim
+        self.text_mask_padding, self.conv_layers, self.pe_attn_head = bool(text_mask_padding), conv_layers, pe_attn_head
+        self.checkpoint_activations = checkpoint_activations  # training-only knob; accepted and ignored
+        prec = precision or os.environ.get("F5HIP_PRECISION", "bf16")
+        self.precision = {"bf16": _lib.F5_PREC_BF16, "fp32": _lib.F5_PREC_FP32}[prec]
+
+        for name, shape, init in _param_spec(dim, depth, heads, dim_head, self.ff_inner, mel_dim, text_num_embeds, text_dim, conv_layers):
+            t = torch.empty(shape)
+            if init == "zeros":
+                t.zero_()
+            elif init == "ones":
+                t.fill_(1.0)
+            elif init == "normal":
+                t.normal_()
+            elif init == "linear":  # torch's default Linear/Conv init: U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+                bound = 1.0 / math.sqrt(math.prod(shape[1:]))
+                t.uniform_(-bound, bound)
+            else:
+                bound = 1.0 / math.sqrt(init[1])
+                t.uniform_(-bound, bound)
+            _register(self, name, t)
+        inv_freq = 1.0 / (10000.0 ** (torch.arange(0, dim_head, 2).float() / dim_head))
+        _register(self, "rotary_embed.inv_freq", inv_freq, buffer=True)
+
+        self.text_cond, self.text_uncond = None, None  # text cache (reference dit.py:131)
+        self._native = None
+        self._plans = []
+        self.register_load_state_dict_post_hook(lambda module, _keys: module._drop_native())
+
+    # ------------------------------------------------------------------ native handle management
+    def _drop_native(self):
+        lib = _lib.load()
+        for _, h in self._plans:
+            lib.f5_plan_destroy(h)
+        self._plans = []
+        if self._native is not None:
+            lib.f5_model_destroy(self._native)
+            self._native = None
+        self.clear_cache()
+
+    def __del__(self):
+        try:
+            self._drop_native()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def native(self):
+        """Upload the current parameter values to HBM in the kernels' layouts (once; redone after load_state_dict)."""
+        if self._native is not None:
+            return self._native
+        _lib.require_gpu()
+        lib = _lib.load()
+        cfg = _lib.DitConfig(dim=self.dim, depth=self.depth, heads=self.heads, dim_head=self.dim_head, ff_inner=self.ff_inner,
+                             mel_dim=self.mel_dim, text_num_embeds=self.text_num_embeds, text_dim=self.text_dim,
+                             conv_layers=self.conv_layers, text_mask_padding=int(self.text_mask_padding),
+                             pe_attn_head=self.pe_attn_head or 0, qk_norm=0, long_skip=0, precision=self.precision)
+        h = C.c_void_p()
+        _lib.check(lib.f5_model_create(C.byref(cfg), C.byref(h)), "model_create")
+        try:
+            _lib.set_tensors(h, "f5_model_set_tensor", "f5_model_has_tensor", self.state_dict())
+            _lib.check(lib.f5_model_finalize(h), "model_finalize")
+        except Exception:
+            lib.f5_model_destroy(h)
+            raise
+        self._native = h
+        return h
+
+    def plan(self, batch, seq, evals=1):
+        """Workspace for (batch, seq) problems; reused while it is large enough."""
+        for (b, n, e), h in self._plans:
+            if b >= batch and n >= seq and e >= evals:
+                return h
+        lib = _lib.load()
+        seq_cap = min(4096, -(-seq // 64) * 64)
+        h = C.c_void_p()
+        _lib.check(lib.f5_plan_create(self.native(), batch, seq_cap, max(evals, 1), C.byref(h)), "plan_create")
+        while len(self._plans) >= 2:  # keep HBM use bounded: drop the oldest bucket
+            lib.f5_plan_destroy(self._plans.pop(0)[1])
+        self._plans.append(((batch, seq_cap, max(evals, 1)), h))
+        return h
+
+    def set_kernels(self, gemm=None, attn=None):
+        """A/B switch between the reference tile kernels (0) and the tuned kernels (1) for existing plans."""
+        lib = _lib.load()
+        for _, h in self._plans:
+            if gemm is not None:
+                _lib.check(lib.f5_plan_set_option(h, b"gemm_kernel", int(gemm)))
+            if attn is not None:
+                _lib.check(lib.f5_plan_set_option(h, b"attn_kernel", int(attn)))
+
+    # ------------------------------------------------------------------ reference API
+    def clear_cache(self):
+        self.text_cond, self.text_uncond = None, None
+
+    def _text_embed(self, plan, text, seq_len, drop_text):
+        lib = _lib.load()
+        b = text.shape[0]
+        ids = text.to(device="cuda", dtype=torch.int32).contiguous()
+        out = torch.empty(b, seq_len, self.text_dim, device="cuda", dtype=torch.float32)
+        _lib.check(lib.f5_text_embed(plan, b, seq_len, _lib.ptr(ids), ids.shape[1], int(bool(drop_text)), _lib.ptr(out), _lib.stream_ptr()),
+                   "text_embed")
+        return out
+
+    def forward(self, x, cond, text, time, drop_audio_cond, drop_text, mask=None, cache=False):
+        lib = _lib.load()
+        batch, seq_len = x.shape[0], x.shape[1]
+        plan = self.plan(batch, seq_len, 1)
+        if time.ndim == 0:
+            time = time.repeat(batch)
+        if cache:
+            if drop_text:
+                if self.text_uncond is None:
+                    self.text_uncond = self._text_embed(plan, text, seq_len, True)
+                text_embed = self.text_uncond
+            else:
+                if self.text_cond is None:
+                    self.text_cond = self._text_embed(plan, text, seq_len, False)
+                text_embed = self.text_cond
+        else:
+            text_embed = self._text_embed(plan, text, seq_len, drop_text)
+        xf = x.to(device="cuda", dtype=torch.float32).contiguous()
+        cf = cond.to(device="cuda", dtype=torch.float32).contiguous()
+        tf = time.to(device="cuda", dtype=torch.float32).contiguous()
+        mk = None if mask is None else mask.to(device="cuda", dtype=torch.uint8).contiguous()
+        out = torch.empty(batch, seq_len, self.mel_dim, device="cuda", dtype=torch.float32)
+        _lib.check(lib.f5_dit_forward(plan, batch, seq_len, _lib.ptr(xf), _lib.ptr(cf), _lib.ptr(text_embed), _lib.ptr(tf),
+                                      int(bool(drop_audio_cond)), _lib.ptr(mk), _lib.ptr(out), _lib.stream_ptr()), "dit_forward")
+        return out.to(x.dtype) if x.dtype != torch.float32 else out
+
+    # ------------------------------------------------------------------ whole-loop entry used by CFM.sample
+    def native_sample(self, cond, text, lens, durations, y0, tgrid, steps, cfg_strength, method="euler", use_mask=True,
+                      return_trajectory=False, use_graph=True):
+        """cond/y0 f32 [B,N,mel] on the GPU, text int [B,nt] (-1 padded), lens/durations int [B], tgrid f32 [steps+1] (any device)."""
+        lib = _lib.load()
+        B, N = cond.shape[0], cond.shape[1]
+        evals = steps * (2 if method == "midpoint" else 1)
+        plan = self.plan(B, N, evals)
+        dev = "cuda"
+        cond = cond.to(device=dev, dtype=torch.float32).contiguous()
+        y0 = y0.to(device=dev, dtype=torch.float32).contiguous()
+        ids = text.to(device=dev, dtype=torch.int32).contiguous()
+        lens32 = lens.to(device=dev, dtype=torch.int32).contiguous()
+        dur32 = durations.to(device=dev, dtype=torch.int32).contiguous() if use_mask else None
+        tg = tgrid.detach().to("cpu", torch.float32).contiguous()
+        out = torch.empty_like(cond)
+        traj = torch.empty(steps + 1, B, N, self.mel_dim, device=dev, dtype=torch.float32) if return_trajectory else None
+        meth = {"euler": _lib.F5_ODE_EULER, "midpoint": _lib.F5_ODE_MIDPOINT}[method]
+        _lib.check(lib.f5_sample(plan, B, N, _lib.ptr(cond), _lib.ptr(ids), ids.shape[1], _lib.ptr(lens32), _lib.ptr(dur32), _lib.ptr(y0),
+                                 C.c_void_p(tg.data_ptr()), steps, float(cfg_strength), meth, _lib.ptr(out), _lib.ptr(traj),
+                                 int(bool(use_graph)), _lib.stream_ptr()), "sample")
+        return out, traj
+
+    def set_tap(self, plan, name, dst):
+        _lib.check(_lib.load().f5_plan_set_tap(plan, None if name is None else name.encode(), _lib.ptr(dst)))

@@ -1,0 +1,170 @@
+/*
+ * f5hip.h -- C ABI of libf5hip.so: the MI355X (gfx950) implementation of the F5-TTS flow-matching
+ * inference hot path (CFM.sample -> DiT ODE loop -> Vocos), written from scratch in HIP.
+ *
+ * The reference (hungkq-1724/EraXviF5TTS) is 100 % Python and has no native ABI; the entry points below
+ * are what a binding for the reference's two plug points would call:
+ *
+ *   plug point A  "backbone class"   f5_tts/infer/f5tts_wrapper.py:134,145  model_cls(**arch, ...)
+ *                                    f5_tts/model/cfm.py:164-172            transformer(x, cond, text, time, ...)
+ *   plug point B  "vocoder object"   f5_tts/infer/utils_infer.py:101-124    load_vocoder(...)
+ *                                    f5_tts/infer/f5tts_wrapper.py:524      vocoder.decode(mel)
+ *   sampler                          f5_tts/model/cfm.py:82-208             CFM.sample(...)
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative F5_E* code on failure; f5_last_error() returns a
+ *     thread-local human readable message.  Nothing throws across the boundary.
+ *   - "dev" pointers are device (HBM) pointers owned by the caller (e.g. torch tensor data_ptr());
+ *     "host" pointers are ordinary host memory.  The library never frees or reallocates caller memory.
+ *   - all work is enqueued on the caller's hipStream_t (f5_stream_t); the library only synchronises
+ *     inside f5_*_create / f5_model_finalize (uploads) and never on the hot path.
+ *   - handles are not thread-safe; distinct handles may be used from distinct threads/processes.
+ *   - there is NO CPU fallback: every entry point fails with F5_ENODEVICE when no gfx950 device is usable.
+ */
+#ifndef F5HIP_H
+#define F5HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define F5HIP_VERSION 100 /* 0.1.0 */
+
+/* error codes */
+#define F5_OK 0
+#define F5_EINVAL -1    /* bad argument / shape */
+#define F5_ENODEVICE -2 /* no usable HIP device */
+#define F5_EHIP -3      /* a HIP runtime call failed (message has the hipError string) */
+#define F5_ESTATE -4    /* call out of order (e.g. forward before finalize) */
+#define F5_ENOTSUP -5   /* configuration the kernels do not implement (qk_norm, long_skip_connection) */
+#define F5_ENOMEM -6
+
+/* arithmetic of the dense kernels */
+#define F5_PREC_BF16 0 /* bf16 MFMA inputs, fp32 accumulate, fp32 residual stream / ODE state (production) */
+#define F5_PREC_FP32 1 /* fp32-input MFMA everywhere (debug / parity mode, ~1/16 of the bf16 rate) */
+
+/* ODE solvers of torchdiffeq's fixed-grid family used by cfm.py:197 */
+#define F5_ODE_EULER 0
+#define F5_ODE_MIDPOINT 1
+
+typedef void* f5_stream_t; /* hipStream_t */
+typedef struct f5_model_s* f5_model_t;
+typedef struct f5_plan_s* f5_plan_t;
+typedef struct f5_vocoder_s* f5_vocoder_t;
+
+/* mirrors the kwargs of DiT.__init__ (f5_tts/model/backbones/dit.py:104-122) */
+typedef struct f5_dit_config {
+    int32_t dim;               /* model width (1024) */
+    int32_t depth;             /* number of DiT blocks (22) */
+    int32_t heads;             /* attention heads (16) */
+    int32_t dim_head;          /* 64 (only 64 is implemented) */
+    int32_t ff_inner;          /* int(dim * ff_mult) (2048) */
+    int32_t mel_dim;           /* 100 */
+    int32_t text_num_embeds;   /* vocab size V (embedding table has V+1 rows) */
+    int32_t text_dim;          /* 512 */
+    int32_t conv_layers;       /* ConvNeXtV2 blocks in the text embedder (4) */
+    int32_t text_mask_padding; /* 0 (F5TTS_Base) / 1 (F5TTS_v1_Base) */
+    int32_t pe_attn_head;      /* heads that receive RoPE; <= 0 means all heads (None) */
+    int32_t qk_norm;           /* must be 0 (null in every shipped config) */
+    int32_t long_skip;         /* must be 0 */
+    int32_t precision;         /* F5_PREC_* */
+} f5_dit_config;
+
+const char* f5_last_error(void);
+int f5_version(void);
+/* number of usable gfx950 devices; name_out (>= 64 bytes, may be NULL) receives the arch string of device 0 */
+int f5_device_count(char* name_out);
+
+/* ------------------------------------------------------------------ model (weights resident in HBM) */
+int f5_model_create(const f5_dit_config* cfg, f5_model_t* out);
+/* name = DiT.state_dict() key, data = contiguous host fp32, shape as in the checkpoint.
+ * Unknown names return F5_EINVAL (callers pass strict=False semantics by skipping names themselves). */
+int f5_model_set_tensor(f5_model_t m, const char* name, const float* host_data, const int64_t* shape, int ndim);
+/* returns 1/0 whether `name` is a tensor the model expects (and its element count in *numel if non-NULL) */
+int f5_model_has_tensor(f5_model_t m, const char* name, int64_t* numel);
+/* builds the fused device layouts (QKV concat, split input projection, rearranged grouped-conv taps, bf16 copies) */
+int f5_model_finalize(f5_model_t m);
+int f5_model_destroy(f5_model_t m);
+
+/* ------------------------------------------------------------------ plan (workspace for one (batch, seq) bucket) */
+/* max_batch = utterances per call (CFG doubling is internal), max_seq = frames N, max_evals = network
+ * evaluations times held at once (steps for euler, 2*steps for midpoint). */
+int f5_plan_create(f5_model_t m, int max_batch, int max_seq, int max_evals, f5_plan_t* out);
+int f5_plan_destroy(f5_plan_t p);
+int64_t f5_plan_workspace_bytes(f5_plan_t p);
+
+/* CFM.sample (cfm.py:82-208) after text->ids and duration resolution:
+ *   cond      dev f32 [B, N, mel]  prompt mel zero-padded to N (NOT yet masked by lens: the kernel applies cfm.py:148-150)
+ *   text      dev i32 [B, nt]      token ids, -1 padded (utils.py:88-95)
+ *   lens      dev i32 [B]          prompt lengths in frames (cond_mask = frame < lens)
+ *   durations dev i32 [B] or NULL  total lengths; NULL = no key-padding mask (the batch==1 path, cfm.py:152-155)
+ *   y0        dev f32 [B, N, mel]  initial noise, rows >= duration zero (cfm.py:178-183)
+ *   tgrid     host f32 [steps+1]   time grid after sway sampling (cfm.py:193-195)
+ *   out       dev f32 [B, N, mel]  where(cond_mask, cond, y(1)) (cfm.py:200-202)
+ *   trajectory dev f32 [steps+1, B, N, mel] or NULL
+ * use_graph != 0 replays a hipGraph captured for this exact (B, N, nt, steps, method, cfg on/off, mask on/off). */
+int f5_sample(f5_plan_t p, int B, int N, const float* cond, const int32_t* text, int nt, const int32_t* lens,
+              const int32_t* durations, const float* y0, const float* tgrid_host, int steps, float cfg_strength,
+              int ode_method, float* out, float* trajectory, int use_graph, f5_stream_t stream);
+
+/* TextEmbedding.forward (dit.py:49-79): text ids [B, nt] (-1 padded) -> dev f32 [B, N, text_dim] */
+int f5_text_embed(f5_plan_t p, int B, int N, const int32_t* text, int nt, int drop_text, float* out, f5_stream_t stream);
+
+/* DiT.forward (dit.py:185-233) for one branch:
+ *   x, cond dev f32 [B, N, mel]; text_embed dev f32 [B, N, text_dim] (from f5_text_embed; the Python module owns the
+ *   cond/uncond cache of dit.py:202-210); time dev f32 [B]; mask dev u8 [B, N] or NULL; out dev f32 [B, N, mel]. */
+int f5_dit_forward(f5_plan_t p, int B, int N, const float* x, const float* cond, const float* text_embed,
+                   const float* time, int drop_audio_cond, const uint8_t* mask, float* out, f5_stream_t stream);
+
+/* debug/parity taps: after the next f5_dit_forward / f5_sample evaluation, copy the named internal stage
+ * (converted to f32, row-major [rows, cols]) into `dst` (dev f32).  Names: "t_emb", "input_embed",
+ * "blk<i>.n1", "blk<i>.attn", "blk<i>.out", "final_norm".  Pass dst = NULL to clear all taps. */
+int f5_plan_set_tap(f5_plan_t p, const char* stage, float* dst);
+/* kernel selection for A/B runs: key "gemm_kernel" / "attn_kernel"; value 0 = reference tile kernels, 1 or -1 = tuned
+ * kernels wherever they support the problem (default).  Drops any captured graphs. */
+int f5_plan_set_option(f5_plan_t p, const char* key, int value);
+
+/* ------------------------------------------------------------------ per-op entry points (parity tests, micro-benchmarks) */
+/* out[M,N] = A[M,K] @ W[N,K]^T + bias ; A/W/out f32 dev; computed through the precision's GEMM kernel
+ * (bf16: inputs rounded to bf16 on device, MFMA, f32 accumulate).  act: 0 none, 1 gelu-tanh, 2 gelu-erf, 3 mish.
+ * kernel: 0 = reference tile kernel, 1 = tuned 256x256 LDS-DMA kernel (bf16 only; shapes must be tile multiples). */
+int f5_op_linear(int precision, int kernel, int M, int N, int K, const float* A, const float* W, const float* bias, int act,
+                 float* out, f5_stream_t stream);
+/* LayerNorm(eps 1e-6, no affine) * (1 + scale) + shift ; x f32 [rows, dim]; scale/shift f32 [dim] */
+int f5_op_layernorm_modulate(int rows, int dim, const float* x, const float* scale, const float* shift, float* out,
+                             f5_stream_t stream);
+/* multi-head attention on packed projections: qkv f32 [B, N, 3, H, 64] (already RoPE'd), mask u8 [B,N] or NULL
+ * -> out f32 [B, N, H*64].  kernel: 0 = reference kernel, 1 = tuned flash kernel (bf16). */
+int f5_op_attention(int precision, int kernel, int B, int N, int H, const float* qkv, const uint8_t* mask, float* out,
+                    f5_stream_t stream);
+/* ConvPositionEmbedding (modules.py:167-190): x f32 [B, N, dim] -> mish(conv(mish(conv(x)))) ; weights f32
+ * [dim, dim/16, 31] + bias [dim] (two layers) */
+int f5_op_conv_pos_embed(int precision, int B, int N, int dim, const float* x, const float* w0, const float* b0,
+                         const float* w1, const float* b1, float* out, f5_stream_t stream);
+
+/* ------------------------------------------------------------------ Vocos vocoder (plug point B) */
+typedef struct f5_vocos_config {
+    int32_t n_mels;    /* 100 */
+    int32_t dim;       /* 512 */
+    int32_t inter_dim; /* 1536 */
+    int32_t layers;    /* 8 */
+    int32_t n_fft;     /* 1024 */
+    int32_t hop;       /* 256 */
+} f5_vocos_config;
+int f5_vocoder_create(const f5_vocos_config* cfg, f5_vocoder_t* out);
+int f5_vocoder_set_tensor(f5_vocoder_t v, const char* name, const float* host_data, const int64_t* shape, int ndim);
+int f5_vocoder_has_tensor(f5_vocoder_t v, const char* name, int64_t* numel);
+int f5_vocoder_finalize(f5_vocoder_t v);
+int f5_vocoder_destroy(f5_vocoder_t v);
+/* Vocos.decode: mel dev f32 [B, n_mels, T] -> wave dev f32 [B, (T-1)*hop] */
+int f5_vocoder_decode(f5_vocoder_t v, int B, int T, const float* mel, float* wave, f5_stream_t stream);
+/* ISTFT head alone (for the roofline measurement): spec dev f32 [B, T, n_fft+2] (head.out activations:
+ * log-magnitude | phase) -> wave dev f32 [B, (T-1)*hop] */
+int f5_vocoder_istft_head(f5_vocoder_t v, int B, int T, const float* head_out, float* wave, f5_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* F5HIP_H */

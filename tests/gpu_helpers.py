@@ -1,0 +1,67 @@
+"""Shared helpers of the GPU parity tests (everything goes through the C ABI of libf5hip.so)."""
+import ctypes as C
+
+import torch
+
+from eraxvif5tts_amd import _lib
+from eraxvif5tts_amd.model import CFM, DiT
+
+
+def make_dit(arch, vocab, weights, precision):
+    m = DiT(**arch, text_num_embeds=vocab, mel_dim=100, precision=precision)
+    sd = m.state_dict()
+    missing = [k for k in sd if k not in weights and k != "rotary_embed.inv_freq"]
+    assert not missing, missing
+    m.load_state_dict({k: v for k, v in weights.items() if k in sd}, strict=False)
+    return m.cuda()
+
+
+def make_cfm(arch, vocab, weights, precision, method="euler"):
+    m = make_dit(arch, vocab, weights, precision)
+    return CFM(transformer=m, mel_spec_kwargs={"mel_spec_type": "vocos"}, odeint_kwargs={"method": method}).cuda()
+
+
+def op_linear(precision, kernel, A, W, bias=None, act="none"):
+    lib = _lib.load()
+    M, K = A.shape
+    N = W.shape[0]
+    A = A.cuda().float().contiguous()
+    W = W.cuda().float().contiguous()
+    b = None if bias is None else bias.cuda().float().contiguous()
+    out = torch.empty(M, N, device="cuda")
+    _lib.check(lib.f5_op_linear(precision, kernel, M, N, K, _lib.ptr(A), _lib.ptr(W), _lib.ptr(b), _lib.ACT[act], _lib.ptr(out), _lib.stream_ptr()))
+    return out.cpu()
+
+
+def op_attention(precision, kernel, qkv, mask=None):
+    lib = _lib.load()
+    B, N, three, H, dh = qkv.shape
+    assert three == 3 and dh == 64
+    q = qkv.cuda().float().contiguous()
+    mk = None if mask is None else mask.cuda().to(torch.uint8).contiguous()
+    out = torch.empty(B, N, H * 64, device="cuda")
+    _lib.check(lib.f5_op_attention(precision, kernel, B, N, H, _lib.ptr(q), _lib.ptr(mk), _lib.ptr(out), _lib.stream_ptr()))
+    return out.cpu()
+
+
+def op_conv_pos(precision, x, w0, b0, w1, b1):
+    lib = _lib.load()
+    B, N, D = x.shape
+    xs = [t.cuda().float().contiguous() for t in (x, w0, b0, w1, b1)]
+    out = torch.empty(B, N, D, device="cuda")
+    _lib.check(lib.f5_op_conv_pos_embed(precision, B, N, D, *[_lib.ptr(t) for t in xs], _lib.ptr(out), _lib.stream_ptr()))
+    return out.cpu()
+
+
+def op_ln_mod(x, scale, shift):
+    lib = _lib.load()
+    rows, dim = x.shape
+    xs = [t.cuda().float().contiguous() for t in (x, scale, shift)]
+    out = torch.empty(rows, dim, device="cuda")
+    _lib.check(lib.f5_op_layernorm_modulate(rows, dim, *[_lib.ptr(t) for t in xs], _lib.ptr(out), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).float()

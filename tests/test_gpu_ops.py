@@ -1,0 +1,93 @@
+"""Per-op parity of the HIP kernels against the CPU oracle / plain fp32 torch math (through the C ABI).
+
+Tolerances (stated): fp32-input MFMA path rel-L2 <= 2e-6 (accumulation order only); bf16 path, with operands pre-rounded
+to bf16 so only the accumulation order and the output rounding differ, rel-L2 <= 2e-5 for f32 outputs."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+from oracle import cpu_ref
+
+pytestmark = pytest.mark.gpu
+P_BF16, P_FP32 = 0, 1
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    from eraxvif5tts_amd import _lib
+    _lib.require_gpu()
+
+
+@pytest.mark.parametrize("prec", [P_FP32, P_BF16])
+@pytest.mark.parametrize("shape", [(64, 64, 64), (100, 72, 96), (300, 1024, 512), (513, 100, 1024)])
+@pytest.mark.parametrize("act", ["none", "gelu_tanh", "gelu_erf", "mish"])
+def test_linear_tile_kernel(prec, shape, act):
+    import gpu_helpers as G
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    if prec == P_BF16:
+        A, W = G.bf16_round(A), G.bf16_round(W)
+    ref = A.double() @ W.double().t() + b.double()
+    ref = {"none": lambda v: v, "gelu_tanh": lambda v: F.gelu(v, approximate="tanh"), "gelu_erf": F.gelu, "mish": F.mish}[act](ref).float()
+    out = G.op_linear(prec, 0, A, W, b, act)
+    assert rel_l2(out, ref) < (2e-6 if prec == P_FP32 else 2e-5)
+
+
+def test_layernorm_modulate():
+    import gpu_helpers as G
+    g = torch.Generator().manual_seed(3)
+    for rows, dim in ((37, 1024), (5, 128), (9, 768)):
+        x = torch.randn(rows, dim, generator=g) * 3 + 1
+        sc, sh = torch.randn(dim, generator=g) * 0.3, torch.randn(dim, generator=g)
+        ref = cpu_ref._layernorm(x) * (1 + sc) + sh
+        assert rel_l2(G.op_ln_mod(x, sc, sh), ref) < 2e-6
+
+
+def _attn_ref(qkv, mask):
+    q, k, v = [qkv[:, :, i].transpose(1, 2).double() for i in range(3)]  # [B,H,N,64]
+    s = q @ k.transpose(-1, -2) / 8.0
+    if mask is not None:
+        s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
+    o = torch.softmax(s, dim=-1) @ v
+    return o.transpose(1, 2).reshape(qkv.shape[0], qkv.shape[1], -1).float()
+
+
+@pytest.mark.parametrize("prec", [P_FP32, P_BF16])
+@pytest.mark.parametrize("B,N,H,masked", [(2, 56, 2, True), (1, 41, 2, False), (2, 200, 3, True), (1, 64, 16, False)])
+def test_attention_reference_kernel(prec, B, N, H, masked):
+    import gpu_helpers as G
+    g = torch.Generator().manual_seed(N)
+    qkv = torch.randn(B, N, 3, H, 64, generator=g)
+    if prec == P_BF16:
+        qkv = G.bf16_round(qkv)
+    mask = None
+    if masked:
+        lens = torch.tensor([N, max(1, N - 13)][:B])
+        mask = torch.arange(N)[None, :] < lens[:, None]
+    ref = _attn_ref(qkv, mask)
+    out = G.op_attention(prec, 0, qkv, mask)
+    tol = 3e-6 if prec == P_FP32 else 4e-3  # bf16: only the final output rounding (8-bit mantissa)
+    assert rel_l2(out, ref) < tol
+
+
+@pytest.mark.parametrize("prec", [P_FP32, P_BF16])
+@pytest.mark.parametrize("dim,B,N", [(128, 2, 50), (1024, 2, 70), (768, 1, 40)])
+def test_conv_pos_embed(prec, dim, B, N):
+    import gpu_helpers as G
+    g = torch.Generator().manual_seed(dim + N)
+    cg = dim // 16
+    x = torch.randn(B, N, dim, generator=g)
+    w0, w1 = [torch.randn(dim, cg, 31, generator=g) / math.sqrt(cg * 31) for _ in range(2)]
+    b0, b1 = torch.randn(dim, generator=g) * 0.1, torch.randn(dim, generator=g) * 0.1
+    if prec == P_BF16:
+        x, w0, w1 = G.bf16_round(x), G.bf16_round(w0), G.bf16_round(w1)
+    W = {"input_embed.conv_pos_embed.conv1d.0.weight": w0, "input_embed.conv_pos_embed.conv1d.0.bias": b0,
+         "input_embed.conv_pos_embed.conv1d.2.weight": w1, "input_embed.conv_pos_embed.conv1d.2.bias": b1}
+    ref = cpu_ref.conv_pos_embed(W, x)
+    out = G.op_conv_pos(prec, x, w0, b0, w1, b1)
+    # bf16: the intermediate activation between the two convolutions is rounded to bf16 (2^-9 relative)
+    assert rel_l2(out, ref) < (3e-6 if prec == P_FP32 else 4e-3)
