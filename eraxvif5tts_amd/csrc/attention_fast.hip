@@ -1,4 +1,214 @@
-// attention_fast.hip -- tuned bf16 flash attention (placeholder: reports "unsupported").
+// attention_fast.hip -- flash attention for the DiT blocks on gfx950 (bf16 in/out, head dim 64, non-causal, key-padding mask).
+//
+// Structure (see /opt/skills/guides/cdna_hip_programming.md, Appendix B "Fused attention prefill"):
+//   * one workgroup = 4 wavefronts = 128 queries of one (batch, head); each wave owns 32 queries; K/V tiles of 64 keys
+//     are double-buffered in LDS (register-staged: the global loads of tile t+2 are issued right after the barrier of
+//     tile t and written to LDS at the end of tile t+1, so their latency hides under a whole tile of MFMA work);
+//   * swapped QK^T: S^T = K.Q^T with v_mfma_f32_32x32x16_bf16, so a lane holds 16 keys x ONE query per 32-key block:
+//     the softmax max/sum are in-register (one cross-half exchange per tile), and the un-normalised P converted to bf16
+//     is directly the B operand of the PV product (accumulator-as-operand k order);
+//   * O^T = V^T.P^T: the V^T fragments come from the row-major V tile through ds_read_b64_tr_b16 (hardware transpose);
+//   * K tile XOR-swizzled for conflict-free ds_read_b128, V tile swizzled for the transposed reads;
+//   * exp2 with the softmax scale folded into one fma; fp32 running max / sum / output accumulators.
 #include "kernels.h"
-bool attention_fast_supported(int, int, int) { return false; }
-int launch_attention_fast(int, int, int, const void*, int, const uint8_t*, void*, int, hipStream_t) { return f5_fail(F5_ENOTSUP, "tuned attention not built"); }
+
+typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& s, int base) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (bf16_t)s[base + j];
+    return r;
+}
+
+template <bool MASKED>
+__global__ __launch_bounds__(256, 2) void attn_fast_kernel(const bf16_t* __restrict__ qkv, int ldq, int inner, const uint8_t* __restrict__ mask,
+                                                           bf16_t* __restrict__ out, int ldo, int N, float c /* scale * log2(e) */) {
+    constexpr int KT = 64;                 // keys per tile
+    constexpr int TILE_BYTES = KT * 128;   // 64 keys x 64 dims x 2 B
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [buf][K | V]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
+    const int r = lane & 31, h = lane >> 5;
+    const bf16_t* base = qkv + (size_t)b * N * ldq + head * 64;
+    const bf16_t* kbase = base + inner;
+    const bf16_t* vbase = base + 2 * inner;
+
+    // ---- Q fragments (B operand: lane holds Q[query r][d = 16*ds + 8*h .. +7]), kept in registers for the whole kernel
+    bf16x8 qf[4];
+    {
+        int qrow = q0 + r;
+        if (qrow >= N) qrow = N - 1;  // clamped rows are computed and dropped
+        const bf16_t* qp = base + (size_t)qrow * ldq + 8 * h;
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) qf[ds] = *reinterpret_cast<const bf16x8*>(qp + 16 * ds);
+    }
+
+    // ---- K/V tile staging: thread t moves chunks t and t+256 (row = chunk>>3, 16-byte column = chunk&7) of K and of V
+    const int srow0 = tid >> 3, scol = tid & 7;  // rows srow0 and srow0 + 32
+    bf16x8 kreg[2], vreg[2];
+    uint8_t mreg = 1;
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int row = k0 + srow0 + 32 * i;
+            if (row >= N) row = N - 1;
+            kreg[i] = *reinterpret_cast<const bf16x8*>(kbase + (size_t)row * ldq + scol * 8);
+            vreg[i] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)row * ldq + scol * 8);
+        }
+        if constexpr (MASKED) {
+            const int key = k0 + lane;
+            mreg = key < N ? (mask ? mask[(size_t)b * N + key] : (uint8_t)1) : (uint8_t)0;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* kb = smem + buf * 2 * TILE_BYTES;
+        char* vb = kb + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = srow0 + 32 * i;
+            *reinterpret_cast<bf16x8*>(kb + row * 128 + ((scol ^ ((row >> 1) & 7)) << 4)) = kreg[i];
+            *reinterpret_cast<bf16x8*>(vb + row * 128 + ((scol ^ (((row >> 1) & 1) << 2)) << 4)) = vreg[i];
+        }
+    };
+
+    // ---- per-lane LDS read offsets
+    // K fragment (A operand of S^T): row = 32*kb + r, logical chunk = 2*ds + h
+    int k_off[4];
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) k_off[ds] = r * 128 + (((2 * ds + h) ^ ((r >> 1) & 7)) << 4);
+    // V^T fragment via ds_read_b64_tr_b16: this lane supplies the address of key row (4*h + ((lane&15)>>2)) [+ 8*g + 16*s + 32*kb],
+    // d columns 16*((lane>>4)&1) + 4*(lane&3) [+ 32*mb]
+    const int v_row = 4 * h + ((lane & 15) >> 2);
+    const int v_colb = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;  // byte column inside the 64-byte half mb
+
+    f32x16 o_acc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o_acc[0][i] = o_acc[1][i] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+
+    const int nt = (N + KT - 1) / KT;
+    load_tile(0);
+    store_tile(0);
+    unsigned long long vm = ~0ull;
+    if constexpr (MASKED) vm = __ballot(mreg != 0);
+    __syncthreads();
+    if (nt > 1) load_tile(KT);
+
+    for (int t = 0; t < nt; ++t) {
+        const char* kb_lds = smem + (t & 1) * 2 * TILE_BYTES;
+        const char* vb_lds = kb_lds + TILE_BYTES;
+
+        // ---- S^T = K . Q^T for the two 32-key blocks of the tile
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb_lds + kb * 32 * 128 + k_off[ds]);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], s[kb], 0, 0, 0);
+            }
+        }
+        // ---- online softmax (this lane: one query, keys 32*kb + (i&3) + 8*(i>>2) + 4*h)
+        if constexpr (MASKED) {
+            if (vm != ~0ull) {
+                const unsigned long long vmh = h ? (vm >> 4) : vm;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int bit = 32 * kb + (i & 3) + 8 * (i >> 2);
+                        if (!((vmh >> bit) & 1ull)) s[kb][i] = -INFINITY;
+                    }
+            }
+        }
+        float mt = s[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mt = fmaxf(mt, s[kb][i]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));  // the other half-wave holds the other 32 keys of the same query
+        const float m_new = fmaxf(m_run, mt * c);  // -inf * c stays -inf; m_run starts finite
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][i], c, -m_new));
+                s[kb][i] = pv;
+                rs += pv;
+            }
+        l_run = l_run * alpha + rs;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            o_acc[0][i] *= alpha;
+            o_acc[1][i] *= alpha;
+        }
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 pf = pack8(s[kb], 8 * ks);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    bf16x8 vf;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const int row = 32 * kb + 16 * ks + 8 * g + v_row;
+                        const int colb = (64 * mb + v_colb) ^ (((row >> 1) & 1) << 6);
+                        const bf16x4 part = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(vb_lds + row * 128 + colb));
+                        vf[4 * g + 0] = part[0];
+                        vf[4 * g + 1] = part[1];
+                        vf[4 * g + 2] = part[2];
+                        vf[4 * g + 3] = part[3];
+                    }
+                    o_acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc[mb], 0, 0, 0);
+                }
+            }
+        // ---- hand the prefetched tile t+1 to LDS, then start fetching tile t+2
+        if (t + 1 < nt) {
+            store_tile((t + 1) & 1);
+            if constexpr (MASKED) vm = __ballot(mreg != 0);
+        }
+        __syncthreads();
+        if (t + 2 < nt) load_tile((t + 2) * KT);
+    }
+
+    // ---- normalise and store: lane holds query q0 + r, dims 32*mb + (i&3) + 8*(i>>2) + 4*h
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    const int qrow = q0 + r;
+    if (qrow < N) {
+        bf16_t* op = out + ((size_t)b * N + qrow) * ldo + head * 64 + 4 * h;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 v4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)(o_acc[mb][4 * g + e] * inv);
+                *reinterpret_cast<bf16x4*>(op + 32 * mb + 8 * g) = v4;
+            }
+    }
+}
+
+bool attention_fast_supported(int precision, int N, int H) { return precision == F5_PREC_BF16 && N >= 1 && H >= 1; }
+
+int launch_attention_fast(int B, int N, int H, const void* qkv, int ldq, const uint8_t* mask, void* out, int ldo, hipStream_t stream) {
+    if ((ldq & 7) || (ldo & 3)) return f5_fail(F5_EINVAL, "attention_fast: ldq must be a multiple of 8 and ldo of 4");
+    const float c = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
+    dim3 grid(cdiv(N, 128), H, B), block(256);
+    const bool masked = mask != nullptr || (N % 64) != 0;
+    if (masked)
+        hipLaunchKernelGGL((attn_fast_kernel<true>), grid, block, 0, stream, (const bf16_t*)qkv, ldq, H * 64, mask, (bf16_t*)out, ldo, N, c);
+    else
+        hipLaunchKernelGGL((attn_fast_kernel<false>), grid, block, 0, stream, (const bf16_t*)qkv, ldq, H * 64, mask, (bf16_t*)out, ldo, N, c);
+    F5_LAUNCH_CHECK();
+    return 0;
+}

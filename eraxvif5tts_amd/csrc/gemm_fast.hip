@@ -1,4 +1,213 @@
-// gemm_fast.hip -- tuned bf16 GEMM (placeholder until the LDS-DMA kernel lands: reports "unsupported").
+// gemm_fast.hip -- tuned bf16 GEMM for gfx950:  out[M,N] = epilogue(A[M,K] . W[N,K]^T), fp32 accumulate.
+//
+// Structure (MI355X-first, see /opt/skills/guides/cdna_hip_programming.md section 5):
+//   * 256-token x BN-feature output tile per 512-thread workgroup (8 wavefronts, one workgroup per CU, 2 waves per SIMD),
+//     K-step 64; v_mfma_f32_16x16x32_bf16 with the weight rows on the MFMA row index, so each lane finishes with 4
+//     consecutive output features of one token (vector stores, lane-local RoPE pairs);
+//   * both operand tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (LDS-DMA, no VGPR staging), double-buffered:
+//     the DMA of K-step t+1 is in flight while the MFMAs of K-step t run; one s_barrier per K-step;
+//   * LDS image is lane-linear (a DMA instruction writes 8 rows x 128 B); bank conflicts of the ds_read_b128 fragment
+//     reads are removed by an XOR swizzle applied on the *source* address and on the read (16-byte chunk ^= (row>>1)&7);
+//   * blockIdx -> tile mapping is XCD-aware (each XCD's L2 sees a contiguous band of token tiles x all feature tiles);
+//   * GEMM_CONV31: the same engine as an implicit GEMM for the grouped Conv1d(k=31): K-steps walk (tap, 64 channels),
+//     the DMA source row is shifted by tap-15 and rows outside the utterance read a zero page.
+//   * rows >= M / features >= N are clamped on load and dropped in the epilogue, so no padding contract on the caller.
 #include "gemm.h"
-bool gemm_fast_supported(const GemmParams&, int, int, int) { return false; }
-int launch_gemm_fast(const GemmParams&, int, int, hipStream_t) { return f5_fail(F5_ENOTSUP, "tuned GEMM not built"); }
+#include "gemm_epilogue.h"
+
+#include <type_traits>
+
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];  // zero-initialised
+
+// compile-time loop: keeps accumulator indices static even when the optimizer refuses a "#pragma unroll"
+// (a runtime-indexed accumulator array would be demoted to scratch memory)
+template <int N, int I = 0, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void dma16(const void* src, char* lds_wave_base) {
+    // wave-uniform LDS base + lane*16 <- 16 bytes from each lane's own global address
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+template <int BN, int WM, int MODE, int EPI>
+__global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(GemmParams p, int tiles_n, int nblocks) {
+    constexpr int BM = 256, BK = 64, WN = 64;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int MI = WM / 16, NI = WN / 16;
+    constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
+    constexpr int WJ = BN / 64;  // weight DMA instructions per wave per K-step
+    static_assert((BM / WM) * WAVES_N == 8, "8 waves");
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    // XCD-aware bijective remap (blocks b and b+8 share an XCD): give each XCD a contiguous band of tiles
+    const int bid = blockIdx.x;
+    const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tile_m = swz / tiles_n, tile_n = swz - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+    const bf16_t* W = reinterpret_cast<const bf16_t*>(p.W);
+
+    // ---- DMA source bookkeeping: 4 A pieces + WJ W pieces per wave per K-step, each piece = 8 rows x 128 B
+    const int prow = lane >> 3, pchunk = lane & 7;
+    const bf16_t* a_src[4];
+    int a_pos[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ra = (wave * 4 + j) * 8 + prow;
+        const int lc = pchunk ^ ((ra >> 1) & 7);  // logical 16-byte chunk stored at this physical slot
+        int gm = m0 + ra;
+        a_ok[j] = gm < p.M;
+        if (gm >= p.M) gm = p.M - 1;
+        if constexpr (MODE == GEMM_DENSE) {
+            if (p.a_row_mod > 0) gm %= p.a_row_mod;
+            a_src[j] = A + (size_t)gm * p.lda + lc * 8;
+            a_pos[j] = 0;
+        } else {
+            a_pos[j] = gm % p.rows_per_batch;
+            a_src[j] = A + (size_t)gm * p.lda + lc * 8;
+        }
+    }
+    const bf16_t* w_src[WJ];
+    int w_lc[WJ];
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+        const int rw = (wave * WJ + j) * 8 + prow;
+        w_lc[j] = pchunk ^ ((rw >> 1) & 7);
+        int gn = n0 + rw;
+        if (gn >= p.N) gn = p.N - 1;
+        if constexpr (MODE == GEMM_DENSE)
+            w_src[j] = W + (size_t)gn * p.ldw + w_lc[j] * 8;
+        else
+            w_src[j] = W + (size_t)gn * p.conv_win + w_lc[j] * 8;
+    }
+    const int cslices = MODE == GEMM_CONV31 ? p.conv_win / BK : 1;
+    const int nk = MODE == GEMM_CONV31 ? 31 * cslices : p.K / BK;
+    const int win0 = MODE == GEMM_CONV31 ? (n0 / p.conv_cg) * p.conv_cg : 0;
+    const int L = p.rows_per_batch;
+
+    auto issue = [&](int kt, int stage) {
+        char* sbase = smem + stage * STAGE;
+        if constexpr (MODE == GEMM_DENSE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dma16(a_src[j] + (size_t)kt * BK, sbase + (wave * 4 + j) * 1024);
+#pragma unroll
+            for (int j = 0; j < WJ; ++j) dma16(w_src[j] + (size_t)kt * BK, sbase + A_BYTES + (wave * WJ + j) * 1024);
+        } else {
+            const int tap = kt / cslices, sl = kt - tap * cslices;
+            const int ch0 = win0 + sl * BK;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int sp = a_pos[j] + tap - 15;
+                const int lc = pchunk ^ ((((wave * 4 + j) * 8 + prow) >> 1) & 7);
+                const bool ok = a_ok[j] && sp >= 0 && sp < L && (ch0 + lc * 8) < p.N;
+                const void* src = ok ? (const void*)(a_src[j] + (ptrdiff_t)(tap - 15) * p.lda + ch0) : (const void*)g_zero_page;
+                dma16(src, sbase + (wave * 4 + j) * 1024);
+            }
+#pragma unroll
+            for (int j = 0; j < WJ; ++j)
+                dma16(w_src[j] + (size_t)tap * p.N * p.conv_win + sl * BK, sbase + A_BYTES + (wave * WJ + j) * 1024);
+        }
+    };
+
+    // ---- fragment read offsets (bytes inside a stage)
+    const int fr = lane & 15, fq = lane >> 4;
+    const int c0 = (fq ^ (fr >> 1)) * 16;
+    const int a_off0 = (wm * WM + fr) * 128 + c0, a_off1 = (wm * WM + fr) * 128 + (c0 ^ 64);
+    const int w_off0 = A_BYTES + (wn * WN + fr) * 128 + c0, w_off1 = A_BYTES + (wn * WN + fr) * 128 + (c0 ^ 64);
+
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        if (kt + 1 < nk) issue(kt + 1, stage ^ 1);
+        const char* sb = smem + stage * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 wf[NI], af[MI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + (ks ? w_off1 : w_off0) + i * 2048);
+#pragma unroll
+            for (int j = 0; j < MI; ++j) af[j] = *reinterpret_cast<const bf16x8*>(sb + (ks ? a_off1 : a_off0) + j * 2048);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next stage landed (this wave's pieces) ...
+        __builtin_amdgcn_s_barrier();                       // ... and every wave is done reading the current one
+    }
+
+    static_for<NI>([&](auto ic) {
+        static_for<MI>([&](auto jc) {
+            constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+            const int n = n0 + wn * WN + i * 16 + 4 * fq;
+            const int m = m0 + wm * WM + j * 16 + fr;
+            gemm_epilogue4<bf16_t, EPI>(p, m, n, acc[i][j]);
+        });
+    });
+}
+
+template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmParams& p, hipStream_t stream) {
+    const int tiles_m = cdiv(p.M, 256), tiles_n = cdiv(p.N, BN);
+    const int nblocks = tiles_m * tiles_n;
+    hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI>), dim3(nblocks), dim3(512), 0, stream, p, tiles_n, nblocks);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+bool gemm_fast_supported(const GemmParams& p, int precision, int mode, int epi) {
+    if (precision != F5_PREC_BF16 || p.M <= 0 || p.N <= 0) return false;
+    if (p.lda & 7) return false;
+    if (mode == GEMM_DENSE) {
+        if (p.K <= 0 || p.K % 64 != 0 || (p.ldw & 7)) return false;
+        return epi >= EPI_STORE_T && epi <= EPI_ROPE_T;
+    }
+    if (mode == GEMM_CONV31) {
+        if (p.conv_win <= 0 || p.conv_win % 64 != 0 || p.N % 64 != 0 || p.conv_cg <= 0 || (p.conv_cg & 7)) return false;
+        if (p.rows_per_batch <= 0 || p.M % p.rows_per_batch != 0) return false;
+        return epi == EPI_STORE_T || epi == EPI_RESID;
+    }
+    return false;
+}
+
+int launch_gemm_fast(const GemmParams& p, int mode, int epi, hipStream_t stream) {
+    if (mode == GEMM_CONV31) {
+        if (epi == EPI_STORE_T) return launch_fast<64, 32, GEMM_CONV31, EPI_STORE_T>(p, stream);
+        if (epi == EPI_RESID) return launch_fast<64, 32, GEMM_CONV31, EPI_RESID>(p, stream);
+        return f5_fail(F5_EINVAL, "gemm_fast(conv31): unsupported epilogue %d", epi);
+    }
+    const bool wide = p.N % 256 == 0;
+#define F5_FAST_CASE(E)                                                         \
+    case E:                                                                     \
+        return wide ? launch_fast<256, 128, GEMM_DENSE, E>(p, stream) : launch_fast<128, 64, GEMM_DENSE, E>(p, stream);
+    switch (epi) {
+        F5_FAST_CASE(EPI_STORE_T)
+        F5_FAST_CASE(EPI_STORE_F32)
+        F5_FAST_CASE(EPI_RESID)
+        F5_FAST_CASE(EPI_ADD2)
+        F5_FAST_CASE(EPI_ROPE_T)
+    }
+#undef F5_FAST_CASE
+    return f5_fail(F5_EINVAL, "gemm_fast: unsupported epilogue %d", epi);
+}

@@ -71,6 +71,7 @@ struct f5_plan_s {
     int gemm_kernel = -1, attn_kernel = -1;  // -1 = auto (tuned kernel when it supports the problem)
     std::map<std::string, float*> taps;
     std::vector<GraphEntry> graphs;
+    hipStream_t cap_stream = nullptr;  // capture happens on a private stream (the caller's may be the legacy null stream)
 };
 
 // ----------------------------------------------------------------------------- model
@@ -391,6 +392,7 @@ extern "C" int f5_plan_destroy(f5_plan_t p) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
         if (g.graph) (void)hipGraphDestroy(g.graph);
     }
+    if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     delete p;
     return 0;
 }
@@ -430,8 +432,9 @@ static GemmParams gp_zero() {
 }
 static int run_gemm(f5_plan_s* p, const GemmParams& g, int mode, int epi, hipStream_t st) {
     const int prec = p->m->cfg.precision;
+    // 1 = tuned kernel wherever it can run; -1 (auto) = tuned kernel once the problem fills the chip with 256-row tiles
     int kind = 0;
-    if (p->gemm_kernel != 0 && gemm_fast_supported(g, prec, mode, epi)) kind = 1;
+    if (p->gemm_kernel != 0 && gemm_fast_supported(g, prec, mode, epi) && (p->gemm_kernel == 1 || g.M >= 2048)) kind = 1;
     return launch_gemm(g, prec, mode, epi, kind, st);
 }
 static float* tap_dst(f5_plan_s* p, const std::string& name) {
@@ -699,9 +702,10 @@ extern "C" int f5_sample(f5_plan_t p, int B, int N, const float* cond, const int
                 ge = &g;
         if (!ge) {
             GraphEntry g{B, N, a.nt, steps, ode_method, a.cfg_on, a.mask_on, a.cfg};
-            F5_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            int rc = sample_body(p, a, st);
-            hipError_t e = hipStreamEndCapture(st, &g.graph);
+            if (!p->cap_stream) F5_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
+            F5_HIP(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeRelaxed));
+            int rc = sample_body(p, a, p->cap_stream);
+            hipError_t e = hipStreamEndCapture(p->cap_stream, &g.graph);
             if (rc != 0) {
                 if (g.graph) (void)hipGraphDestroy(g.graph);
                 return rc;

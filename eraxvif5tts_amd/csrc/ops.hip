@@ -113,3 +113,114 @@ extern "C" int f5_op_conv_pos_embed(int precision, int B, int N, int dim, const 
     } while (0);
     return sync_and_release(a, st, rc);
 }
+
+// ----------------------------------------------------------------------------- in-process kernel timing (bench.py roofline leg)
+__global__ __launch_bounds__(256) void fill_random_kernel(uint16_t* dst, size_t n, uint32_t seed, float scale) {
+    // counter-based hash -> uniform [-scale, scale) in bf16: random operands (zero-filled ones raise the clock and flatter MFMA rates)
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t x = (uint32_t)i * 2654435761u ^ seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    const float u = ((float)(x >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale;
+    dst[i] = (uint16_t)(__float_as_uint(u) >> 16);
+}
+__global__ __launch_bounds__(256) void fill_random_f32_kernel(float* dst, size_t n, uint32_t seed, float scale) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t x = (uint32_t)i * 2654435761u ^ seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    dst[i] = ((float)(x >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale;
+}
+
+// Times `iters` back-to-back launches of ONE GEMM kernel (bf16, the epilogue/shape of the DiT call site `site`) with HIP
+// events on `stream`; *ms_avg = average device time of one launch.  site: 0 = fused QKV projection + RoPE (N = 3*inner),
+// 1 = FF1 + GELU-tanh, 2 = FF2 + gated residual, 3 = attention out-projection + gated residual.
+extern "C" int f5_bench_gemm_site(int kernel, int site, int rows, int seq, int dim, int heads, int ff_inner, int iters, float* ms_avg,
+                                  f5_stream_t stream) {
+    F5_TRY(f5_check_device());
+    if (!ms_avg || rows <= 0 || iters <= 0 || seq <= 0 || rows % seq != 0) return f5_fail(F5_EINVAL, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int inner = heads * 64;
+    int N, K, epi;
+    switch (site) {
+        case 0: N = 3 * inner; K = dim; epi = EPI_ROPE_T; break;
+        case 1: N = ff_inner; K = dim; epi = EPI_STORE_T; break;
+        case 2: N = dim; K = ff_inner; epi = EPI_RESID; break;
+        case 3: N = dim; K = inner; epi = EPI_RESID; break;
+        default: return f5_fail(F5_EINVAL, "bad site");
+    }
+    const size_t Mp = (size_t)round_up(rows, 256);
+    DevArena a;
+    void *A = nullptr, *W = nullptr, *out = nullptr;
+    float *bias = nullptr, *resid = nullptr, *gate = nullptr, *rope = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = 0;
+    do {
+        if ((rc = a.alloc(&A, Mp * K * 2))) break;
+        if ((rc = a.alloc(&W, (size_t)round_up(N, 256) * K * 2))) break;
+        if ((rc = a.alloc(&out, Mp * N * 2))) break;
+        if ((rc = a.alloc_t(&bias, (size_t)N))) break;
+        if ((rc = a.alloc_t(&resid, Mp * (size_t)dim))) break;
+        if ((rc = a.alloc_t(&gate, (size_t)dim))) break;
+        if ((rc = a.alloc_t(&rope, (size_t)seq * 64))) break;
+        hipLaunchKernelGGL(fill_random_kernel, dim3((unsigned)((Mp * K + 255) / 256)), dim3(256), 0, st, (uint16_t*)A, Mp * K, 1u, 1.0f);
+        hipLaunchKernelGGL(fill_random_kernel, dim3((unsigned)(((size_t)N * K + 255) / 256)), dim3(256), 0, st, (uint16_t*)W, (size_t)N * K, 2u, 0.05f);
+        hipLaunchKernelGGL(fill_random_f32_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, bias, (size_t)N, 3u, 0.1f);
+        hipLaunchKernelGGL(fill_random_f32_kernel, dim3((unsigned)((dim + 255) / 256)), dim3(256), 0, st, gate, (size_t)dim, 4u, 0.01f);
+        hipLaunchKernelGGL(fill_random_f32_kernel, dim3((unsigned)((seq * 64 + 255) / 256)), dim3(256), 0, st, rope, (size_t)seq * 64, 5u, 0.7f);
+        GemmParams g;
+        memset(&g, 0, sizeof(g));
+        g.A = A; g.lda = K; g.W = W; g.ldw = K; g.M = rows; g.N = N; g.K = K; g.bias = bias; g.rows_per_batch = seq;
+        if (epi == EPI_ROPE_T) { g.out_t = out; g.ldo = N; g.rope = rope; g.rope_inner = inner; g.rope_heads = 1; }
+        if (epi == EPI_STORE_T) { g.out_t = out; g.ldo = N; g.act = ACT_GELU_TANH; }
+        if (epi == EPI_RESID) { g.out_f = resid; g.ldof = dim; g.gate = gate; g.gate_bstride = 0; }
+        if (kernel == 1 && !gemm_fast_supported(g, F5_PREC_BF16, GEMM_DENSE, epi)) { rc = f5_fail(F5_ENOTSUP, "tuned kernel cannot run this site"); break; }
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { rc = f5_fail(F5_EHIP, "hipEventCreate failed"); break; }
+        for (int i = 0; i < 2 && rc == 0; ++i) rc = launch_gemm(g, F5_PREC_BF16, GEMM_DENSE, epi, kernel, st);
+        if (rc) break;
+        (void)hipEventRecord(e0, st);
+        for (int i = 0; i < iters && rc == 0; ++i) rc = launch_gemm(g, F5_PREC_BF16, GEMM_DENSE, epi, kernel, st);
+        (void)hipEventRecord(e1, st);
+        if (rc) break;
+        if (hipEventSynchronize(e1) != hipSuccess) { rc = f5_fail(F5_EHIP, "event sync failed: %s", hipGetErrorString(hipGetLastError())); break; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *ms_avg = ms / (float)iters;
+    } while (0);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return sync_and_release(a, st, rc);
+}
+
+// same for the attention kernel: B x H heads of N x 64, bf16
+extern "C" int f5_bench_attention(int kernel, int B, int N, int H, int iters, float* ms_avg, f5_stream_t stream) {
+    F5_TRY(f5_check_device());
+    if (!ms_avg || B <= 0 || N <= 0 || H <= 0 || iters <= 0) return f5_fail(F5_EINVAL, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int inner = H * 64;
+    const size_t rows = (size_t)B * N;
+    DevArena a;
+    void *q = nullptr, *o = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = 0;
+    do {
+        if ((rc = a.alloc(&q, rows * 3 * inner * 2))) break;
+        if ((rc = a.alloc(&o, rows * inner * 2))) break;
+        hipLaunchKernelGGL(fill_random_kernel, dim3((unsigned)((rows * 3 * inner + 255) / 256)), dim3(256), 0, st, (uint16_t*)q, rows * 3 * inner, 7u, 1.5f);
+        if (kernel == 1 && !attention_fast_supported(F5_PREC_BF16, N, H)) { rc = f5_fail(F5_ENOTSUP, "tuned attention cannot run this shape"); break; }
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { rc = f5_fail(F5_EHIP, "hipEventCreate failed"); break; }
+        for (int i = 0; i < 2 && rc == 0; ++i) rc = launch_attention(F5_PREC_BF16, kernel, B, N, H, q, 3 * inner, nullptr, o, inner, st);
+        if (rc) break;
+        (void)hipEventRecord(e0, st);
+        for (int i = 0; i < iters && rc == 0; ++i) rc = launch_attention(F5_PREC_BF16, kernel, B, N, H, q, 3 * inner, nullptr, o, inner, st);
+        (void)hipEventRecord(e1, st);
+        if (rc) break;
+        if (hipEventSynchronize(e1) != hipSuccess) { rc = f5_fail(F5_EHIP, "event sync failed"); break; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *ms_avg = ms / (float)iters;
+    } while (0);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return sync_and_release(a, st, rc);
+}

@@ -144,6 +144,13 @@ int f5_op_attention(int precision, int kernel, int B, int N, int H, const float*
 int f5_op_conv_pos_embed(int precision, int B, int N, int dim, const float* x, const float* w0, const float* b0,
                          const float* w1, const float* b1, float* out, f5_stream_t stream);
 
+/* in-process kernel timing for the roofline leg of bench.py: `iters` back-to-back launches of ONE kernel bracketed by HIP
+ * events on `stream`, random bf16 operands; *ms_avg = mean device time per launch.
+ * site: 0 fused QKV projection + RoPE, 1 FF1 + GELU-tanh, 2 FF2 + gated residual, 3 attention out-projection + gated residual. */
+int f5_bench_gemm_site(int kernel, int site, int rows, int seq, int dim, int heads, int ff_inner, int iters, float* ms_avg,
+                       f5_stream_t stream);
+int f5_bench_attention(int kernel, int B, int N, int H, int iters, float* ms_avg, f5_stream_t stream);
+
 /* ------------------------------------------------------------------ Vocos vocoder (plug point B) */
 typedef struct f5_vocos_config {
     int32_t n_mels;    /* 100 */

@@ -20,6 +20,16 @@ def _gpu():
     _lib.require_gpu()
 
 
+@pytest.fixture(params=["reference-kernels", "tuned-kernels"], autouse=True)
+def kernels(request, monkeypatch):
+    """every model-level test runs twice: reference tile kernels only / tuned kernels forced wherever they support the
+    problem (fp32 mode always uses the fp32-input MFMA tile kernels)."""
+    v = "0" if request.param == "reference-kernels" else "1"
+    monkeypatch.setenv("F5HIP_GEMM_KERNEL", v)
+    monkeypatch.setenv("F5HIP_ATTN_KERNEL", v)
+    return request.param
+
+
 def _gen_rows(t, dur):
     """concatenate the rows < duration of every batch element (what callers slice out)."""
     return torch.cat([t[..., b, : int(d), :].reshape(-1, t.shape[-1]) for b, d in enumerate(dur)])

@@ -91,3 +91,51 @@ def test_conv_pos_embed(prec, dim, B, N):
     out = G.op_conv_pos(prec, x, w0, b0, w1, b1)
     # bf16: the intermediate activation between the two convolutions is rounded to bf16 (2^-9 relative)
     assert rel_l2(out, ref) < (3e-6 if prec == P_FP32 else 4e-3)
+
+
+# ----------------------------------------------------------------------------- tuned kernels (bf16) vs the same references
+@pytest.mark.parametrize("shape", [(256, 256, 64), (512, 1024, 1024), (300, 3072, 128), (1000, 100, 1024), (2048, 2048, 2048), (77, 512, 640)])
+@pytest.mark.parametrize("act", ["none", "gelu_tanh"])
+def test_linear_tuned_kernel(shape, act):
+    import gpu_helpers as G
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    A, W, b = G.bf16_round(torch.randn(M, K, generator=g)), G.bf16_round(torch.randn(N, K, generator=g) / math.sqrt(K)), torch.randn(N, generator=g)
+    ref = A.double() @ W.double().t() + b.double()
+    ref = (F.gelu(ref, approximate="tanh") if act == "gelu_tanh" else ref).float()
+    out = G.op_linear(P_BF16, 1, A, W, b, act)
+    assert rel_l2(out, ref) < 2e-5
+    # and bit-for-bit the same contraction as the reference tile kernel up to fp32 summation order
+    assert rel_l2(out, G.op_linear(P_BF16, 0, A, W, b, act)) < 2e-5
+
+
+@pytest.mark.parametrize("B,N,H,masked", [(2, 56, 2, True), (1, 41, 2, False), (2, 200, 3, True), (1, 128, 16, False), (2, 1024, 4, True),
+                                          (1, 1024, 2, False), (3, 333, 1, True)])
+def test_attention_tuned_kernel(B, N, H, masked):
+    import gpu_helpers as G
+    g = torch.Generator().manual_seed(N + H)
+    qkv = G.bf16_round(torch.randn(B, N, 3, H, 64, generator=g) * 1.5)
+    mask = None
+    if masked:
+        lens = torch.tensor([N, max(1, N - 13), max(1, N // 2)][:B])
+        mask = torch.arange(N)[None, :] < lens[:, None]
+    ref = _attn_ref(qkv, mask)
+    out = G.op_attention(P_BF16, 1, qkv, mask)
+    # P is rounded to bf16 before the PV product and the output is bf16: 2^-9 relative each
+    assert rel_l2(out, ref) < 6e-3
+    valid = slice(None) if mask is None else mask
+    assert torch.isfinite(out).all()
+    assert (out[valid] - ref[valid]).abs().max() < 0.05
+
+
+def test_attention_tuned_kernel_spiked_scores():
+    """online-softmax rescale path: one key dominates late in the sequence (running max jumps by > 60)."""
+    import gpu_helpers as G
+    g = torch.Generator().manual_seed(5)
+    B, N, H = 1, 512, 2
+    qkv = G.bf16_round(torch.randn(B, N, 3, H, 64, generator=g))
+    qkv[0, 400, 1] = qkv[0, 7, 0] * 8.0  # key 400 aligned with query 7
+    qkv = G.bf16_round(qkv)
+    ref = _attn_ref(qkv, None)
+    out = G.op_attention(P_BF16, 1, qkv, None)
+    assert rel_l2(out, ref) < 6e-3
