@@ -4,14 +4,17 @@
 #include "kernels.h"
 
 // ----------------------------------------------------------------------------- LayerNorm (+ modulation)
-template <typename TO, int MAXV>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, int rows, int dim, const float* __restrict__ mul,
-                                                        const float* __restrict__ add, int mod_bstride, int rows_per_batch, float add_one,
-                                                        TO* __restrict__ out, int ldo) {
+// x[r] (+= y[r], written back) -> out[r] = LN(x[r]) * (add_one + mul[b]) + add[b].  The optional y is the previous
+// residual branch (gate * (attention | feed-forward) output in the activation dtype): folding the fp32 residual add into
+// this streaming pass keeps the GEMM epilogues store-only and the read-modify-write fully coalesced.
+template <typename TO, int MAXV, bool HAS_Y>
+__global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, int ldx, int rows, int dim, const TO* __restrict__ y, int ldy,
+                                                        const float* __restrict__ mul, const float* __restrict__ add, int mod_bstride,
+                                                        int rows_per_batch, float add_one, TO* __restrict__ out, int ldo) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* xr = x + (size_t)row * ldx;
+    float* xr = x + (size_t)row * ldx;
     const int nvec = dim >> 2;  // dim % 4 == 0
     f32x4 v[MAXV];
     float s = 0.f;
@@ -20,6 +23,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const int c = lane + i * 64;
         if (c < nvec) {
             v[i] = *reinterpret_cast<const f32x4*>(xr + c * 4);
+            if constexpr (HAS_Y) {
+                const TO* yr = y + (size_t)row * ldy + c * 4;
+                if constexpr (sizeof(TO) == 2) {
+                    const bf16x4 y4 = *reinterpret_cast<const bf16x4*>(yr);
+                    v[i] += f32x4{(float)y4[0], (float)y4[1], (float)y4[2], (float)y4[3]};
+                } else {
+                    v[i] += *reinterpret_cast<const f32x4*>(yr);
+                }
+                *reinterpret_cast<f32x4*>(xr + c * 4) = v[i];
+            }
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
     }
@@ -57,26 +70,44 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
-int launch_layernorm(int precision_out, const float* x, int ldx, int rows, int dim, const float* mul, const float* add, int mod_bstride,
-                     int rows_per_batch, int add_one, void* out, int ldo, hipStream_t stream) {
-    if (rows <= 0) return 0;
-    if (dim % 4 != 0 || dim > 2048 || (ldx & 3) || (ldo & 3) || (mod_bstride & 3)) return f5_fail(F5_EINVAL, "layernorm: dim=%d unsupported", dim);
-    if (rows_per_batch <= 0) rows_per_batch = rows;
+template <typename TO, int MAXV>
+static void ln_launch(float* x, int ldx, int rows, int dim, const void* y, int ldy, const float* mul, const float* add, int mod_bstride,
+                      int rows_per_batch, float one, void* out, int ldo, hipStream_t stream) {
     dim3 grid(cdiv(rows, 4)), block(256);
+    if (y)
+        hipLaunchKernelGGL((layernorm_kernel<TO, MAXV, true>), grid, block, 0, stream, x, ldx, rows, dim, (const TO*)y, ldy, mul, add, mod_bstride,
+                           rows_per_batch, one, (TO*)out, ldo);
+    else
+        hipLaunchKernelGGL((layernorm_kernel<TO, MAXV, false>), grid, block, 0, stream, x, ldx, rows, dim, (const TO*)nullptr, 0, mul, add,
+                           mod_bstride, rows_per_batch, one, (TO*)out, ldo);
+}
+
+int launch_layernorm_add(int precision_out, float* x, int ldx, int rows, int dim, const void* y, int ldy, const float* mul, const float* add,
+                         int mod_bstride, int rows_per_batch, int add_one, void* out, int ldo, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    if (dim % 4 != 0 || dim > 2048 || (ldx & 3) || (ldo & 3) || (mod_bstride & 3) || (y && (ldy & 3)))
+        return f5_fail(F5_EINVAL, "layernorm: dim=%d unsupported", dim);
+    if (rows_per_batch <= 0) rows_per_batch = rows;
     const float one = add_one ? 1.0f : 0.0f;
     if (precision_out == F5_PREC_BF16) {
         if (dim <= 1024)
-            hipLaunchKernelGGL((layernorm_kernel<bf16_t, 4>), grid, block, 0, stream, x, ldx, rows, dim, mul, add, mod_bstride, rows_per_batch, one, (bf16_t*)out, ldo);
+            ln_launch<bf16_t, 4>(x, ldx, rows, dim, y, ldy, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream);
         else
-            hipLaunchKernelGGL((layernorm_kernel<bf16_t, 8>), grid, block, 0, stream, x, ldx, rows, dim, mul, add, mod_bstride, rows_per_batch, one, (bf16_t*)out, ldo);
+            ln_launch<bf16_t, 8>(x, ldx, rows, dim, y, ldy, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream);
     } else {
         if (dim <= 1024)
-            hipLaunchKernelGGL((layernorm_kernel<float, 4>), grid, block, 0, stream, x, ldx, rows, dim, mul, add, mod_bstride, rows_per_batch, one, (float*)out, ldo);
+            ln_launch<float, 4>(x, ldx, rows, dim, y, ldy, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream);
         else
-            hipLaunchKernelGGL((layernorm_kernel<float, 8>), grid, block, 0, stream, x, ldx, rows, dim, mul, add, mod_bstride, rows_per_batch, one, (float*)out, ldo);
+            ln_launch<float, 8>(x, ldx, rows, dim, y, ldy, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream);
     }
     F5_LAUNCH_CHECK();
     return 0;
+}
+
+int launch_layernorm(int precision_out, const float* x, int ldx, int rows, int dim, const float* mul, const float* add, int mod_bstride,
+                     int rows_per_batch, int add_one, void* out, int ldo, hipStream_t stream) {
+    return launch_layernorm_add(precision_out, const_cast<float*>(x), ldx, rows, dim, nullptr, 0, mul, add, mod_bstride, rows_per_batch, add_one,
+                                out, ldo, stream);
 }
 
 // ----------------------------------------------------------------------------- depthwise conv k=7 + LayerNorm(affine)

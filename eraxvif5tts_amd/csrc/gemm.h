@@ -17,7 +17,9 @@ enum GemmEpi {
     EPI_STORE_F32 = 1,  // out_f[m][n]  = act(acc + bias[n])                                (f32)
     EPI_RESID = 2,      // out_f[m][n] += gate[b(m)][n] * act(acc + bias[n]), skipped where rowmask[m]==0
     EPI_ADD2 = 3,       // v = acc + bias[n] + addend[m][n];  out_t[m][n] = v;  out_f[m][n] = v
-    EPI_ROPE_T = 4      // out_t = rope(acc + bias) on the q/k columns of the first pe heads (fused QKV projection)
+    EPI_ROPE_T = 4,     // out_t = rope(acc + bias) on the q/k columns of the first pe heads (fused QKV projection)
+    EPI_GATE_T = 5      // out_t[m][n] = gate[b(m)][n] * act(acc + bias[n]), 0 where rowmask[m]==0  (store-only residual branch;
+                        // the fp32 residual add itself is fused into the next LayerNorm pass)
 };
 
 struct GemmParams {

@@ -151,11 +151,13 @@ template <typename T> static int dispatch_tile(const GemmParams& p, int mode, in
             case EPI_RESID: return launch_tile<T, GEMM_DENSE, EPI_RESID>(p, stream);
             case EPI_ADD2: return launch_tile<T, GEMM_DENSE, EPI_ADD2>(p, stream);
             case EPI_ROPE_T: return launch_tile<T, GEMM_DENSE, EPI_ROPE_T>(p, stream);
+            case EPI_GATE_T: return launch_tile<T, GEMM_DENSE, EPI_GATE_T>(p, stream);
         }
     } else {
         switch (epi) {
             case EPI_STORE_T: return launch_tile<T, GEMM_CONV31, EPI_STORE_T>(p, stream);
             case EPI_RESID: return launch_tile<T, GEMM_CONV31, EPI_RESID>(p, stream);
+            case EPI_GATE_T: return launch_tile<T, GEMM_CONV31, EPI_GATE_T>(p, stream);
         }
     }
     return f5_fail(F5_EINVAL, "gemm: unsupported mode/epilogue %d/%d", mode, epi);
@@ -172,7 +174,7 @@ int launch_gemm(const GemmParams& p, int precision, int mode, int epi, int kerne
             (p.conv_cg & 7) || p.conv_win % 32 != 0)
             return f5_fail(F5_EINVAL, "gemm(conv31): N must be a multiple of 64, M a whole number of sequences, group size a multiple of 8");
     }
-    if ((epi == EPI_RESID || epi == EPI_ROPE_T) && p.rows_per_batch <= 0) return f5_fail(F5_EINVAL, "gemm: rows_per_batch missing");
+    if ((epi == EPI_RESID || epi == EPI_ROPE_T || epi == EPI_GATE_T) && p.rows_per_batch <= 0) return f5_fail(F5_EINVAL, "gemm: rows_per_batch missing");
     if (kernel_kind == 1) {
         if (!gemm_fast_supported(p, precision, mode, epi)) return f5_fail(F5_EINVAL, "gemm: tuned kernel does not support this problem");
         return launch_gemm_fast(p, mode, epi, stream);

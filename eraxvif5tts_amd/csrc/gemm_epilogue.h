@@ -71,6 +71,17 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmParams& p, int m, int n
             }
         }
         store4_t<float>(dst, o, vec, nvalid);
+    } else if constexpr (EPI == EPI_GATE_T) {
+        const bool keep = !(p.rowmask && p.rowmask[m] == 0);  // padded query rows: attention output masked_fill'd to 0 (modules.py:499-501)
+        const float* g = p.gate ? p.gate + (size_t)(m / p.rows_per_batch) * p.gate_bstride + n : nullptr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float t = apply_act(v[r], p.act);
+            if (g && r < nvalid) t *= g[r];
+            v[r] = keep ? t : 0.f;
+        }
+        const bool vec = nvalid == 4 && (p.ldo & 3) == 0;
+        store4_t<T>(reinterpret_cast<T*>(p.out_t) + (size_t)m * p.ldo + n, v, vec, nvalid);
     } else if constexpr (EPI == EPI_ADD2) {
         const float* a = p.addend + (size_t)m * p.ldadd + n;
 #pragma unroll

@@ -13,8 +13,6 @@
 //     the DMA source row is shifted by tap-15 and rows outside the utterance read a zero page.
 //   * rows >= M / features >= N are clamped on load and dropped in the epilogue, so no padding contract on the caller.
 #include "gemm.h"
-#include "gemm_epilogue.h"
-
 #include <type_traits>
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];  // zero-initialised
@@ -27,6 +25,21 @@ template <int N, int I = 0, typename F> __device__ __forceinline__ void static_f
         static_for<N, I + 1>(f);
     }
 }
+
+// exp2/rcp forms of the activations for the bf16 epilogues (the output rounding to bf16 dominates their ~1 ulp error):
+//   gelu_tanh(x) = 0.5 x (1 + tanh(u)) = x * sigmoid(2u),  u = sqrt(2/pi) (x + 0.044715 x^3)
+//   mish(x)      = x tanh(softplus(x)) = x * n / (n + 2),  n = e^x (e^x + 2)
+__device__ __forceinline__ float fast_gelu_tanh(float x) {
+    const float a = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
+    const float u2 = x * (a + (a * 0.044715f) * (x * x));
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u2));
+}
+__device__ __forceinline__ float fast_mish(float x) {
+    const float w = __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+    const float n = w * (w + 2.0f);
+    return x > 20.0f ? x : x * n * __builtin_amdgcn_rcpf(n + 2.0f);
+}
+__device__ __forceinline__ bf16x4 to_bf16x4(const f32x4& v) { return bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]}; }
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -128,6 +141,28 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
     const int a_off0 = (wm * WM + fr) * 128 + c0, a_off1 = (wm * WM + fr) * 128 + (c0 ^ 64);
     const int w_off0 = A_BYTES + (wn * WN + fr) * 128 + c0, w_off1 = A_BYTES + (wn * WN + fr) * 128 + (c0 ^ 64);
 
+    // ---- epilogue operands that do not depend on the token are fetched now, so their latency hides under the main loop
+    int ncol[NI];
+    bool okn[NI];
+    f32x4 bias4[NI];
+    [[maybe_unused]] f32x4 gate4[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int n = n0 + wn * WN + i * 16 + 4 * fq;
+        okn[i] = n + 3 < p.N;  // N % 4 == 0: a lane's 4 features are valid together
+        ncol[i] = okn[i] ? n : 0;
+        bias4[i] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ncol[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI == EPI_GATE_T || EPI == EPI_RESID)
+            gate4[i] = (p.gate && p.gate_bstride == 0) ? *reinterpret_cast<const f32x4*>(p.gate + ncol[i]) : f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+    // fused QKV projection: a wave's 64 features are exactly one head of q, k or v -> RoPE applies to the whole wave tile or not at all
+    [[maybe_unused]] bool rope_wave = false;
+    if constexpr (EPI == EPI_ROPE_T) {
+        const int nw = n0 + wn * WN;
+        const int part = nw / p.rope_inner;
+        rope_wave = part < 2 && ((nw - part * p.rope_inner) >> 6) < p.rope_heads;
+    }
+
     f32x4 acc[NI][MI];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -158,12 +193,98 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
         __builtin_amdgcn_s_barrier();                       // ... and every wave is done reading the current one
     }
 
-    static_for<NI>([&](auto ic) {
-        static_for<MI>([&](auto jc) {
-            constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
-            const int n = n0 + wn * WN + i * 16 + 4 * fq;
-            const int m = m0 + wm * WM + j * 16 + fr;
-            gemm_epilogue4<bf16_t, EPI>(p, m, n, acc[i][j]);
+    // ---------------------------------------------------------------- epilogue (store-only wherever the call site allows)
+    // Loads (row mask, RoPE table, addend / residual) are issued in groups BEFORE any store of the group: vmcnt retires
+    // in order, so a load issued behind a store would also wait for that store's round trip.
+    constexpr int JG = (EPI == EPI_RESID || EPI == EPI_GATE_T) ? 2 : (MI >= 4 ? 4 : MI);  // token tiles per load group (register budget)
+    static_for<MI / JG>([&](auto gc) {
+        constexpr int j0 = decltype(gc)::value * JG;
+        int mrow[JG];
+        bool okm[JG];
+#pragma unroll
+        for (int jj = 0; jj < JG; ++jj) {
+            const int m = m0 + wm * WM + (j0 + jj) * 16 + fr;
+            okm[jj] = m < p.M;
+            mrow[jj] = okm[jj] ? m : p.M - 1;
+        }
+        [[maybe_unused]] f32x4 aux[JG][NI];
+        [[maybe_unused]] bool keep[JG];
+        if constexpr (EPI == EPI_GATE_T) {
+#pragma unroll
+            for (int jj = 0; jj < JG; ++jj) keep[jj] = p.rowmask ? p.rowmask[mrow[jj]] != 0 : true;
+            if (p.gate && p.gate_bstride != 0) {  // per-sample time (DiT.forward with a time vector): gate row depends on the token's batch
+#pragma unroll
+                for (int jj = 0; jj < JG; ++jj)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+                        aux[jj][i] = *reinterpret_cast<const f32x4*>(p.gate + (size_t)(mrow[jj] / p.rows_per_batch) * p.gate_bstride + ncol[i]);
+            }
+        } else if constexpr (EPI == EPI_ROPE_T) {
+            if (rope_wave) {
+#pragma unroll
+                for (int jj = 0; jj < JG; ++jj) {
+                    const int pos = mrow[jj] % p.rows_per_batch;
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) aux[jj][i] = *reinterpret_cast<const f32x4*>(p.rope + (size_t)pos * 64 + 16 * i + 4 * fq);
+                }
+            }
+        } else if constexpr (EPI == EPI_ADD2) {
+#pragma unroll
+            for (int jj = 0; jj < JG; ++jj)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) aux[jj][i] = *reinterpret_cast<const f32x4*>(p.addend + (size_t)mrow[jj] * p.ldadd + ncol[i]);
+        } else if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+            for (int jj = 0; jj < JG; ++jj) {
+                keep[jj] = p.rowmask ? p.rowmask[mrow[jj]] != 0 : true;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) aux[jj][i] = *reinterpret_cast<const f32x4*>(p.out_f + (size_t)mrow[jj] * p.ldof + ncol[i]);
+            }
+        }
+        static_for<JG>([&](auto jc) {
+            constexpr int jj = decltype(jc)::value;
+            static_for<NI>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                f32x4 v = acc[i][j0 + jj] + bias4[i];
+                const bool ok = okm[jj] && okn[i];
+                const size_t mr = (size_t)mrow[jj];
+                if constexpr (EPI == EPI_STORE_T || EPI == EPI_STORE_F32 || EPI == EPI_GATE_T || EPI == EPI_RESID) {
+                    if (p.act == ACT_GELU_TANH) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fast_gelu_tanh(v[e]);
+                    } else if (p.act == ACT_MISH) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fast_mish(v[e]);
+                    } else if (p.act == ACT_GELU_ERF) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = act_gelu_erf(v[e]);
+                    }
+                }
+                if constexpr (EPI == EPI_STORE_T) {
+                    if (ok) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.out_t) + mr * p.ldo + ncol[i]) = to_bf16x4(v);
+                } else if constexpr (EPI == EPI_STORE_F32) {
+                    if (ok) *reinterpret_cast<f32x4*>(p.out_f + mr * p.ldof + ncol[i]) = v;
+                } else if constexpr (EPI == EPI_GATE_T) {
+                    if (p.gate) v *= (p.gate_bstride != 0 ? aux[jj][i] : gate4[i]);
+                    if (!keep[jj]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (ok) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.out_t) + mr * p.ldo + ncol[i]) = to_bf16x4(v);
+                } else if constexpr (EPI == EPI_ROPE_T) {
+                    if (rope_wave) {  // x_transformers apply_rotary_pos_emb: adjacent pairs, fp32 math
+                        const f32x4 cs = aux[jj][i];
+                        v = f32x4{v[0] * cs[0] - v[1] * cs[1], v[1] * cs[0] + v[0] * cs[1], v[2] * cs[2] - v[3] * cs[3], v[3] * cs[2] + v[2] * cs[3]};
+                    }
+                    if (ok) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.out_t) + mr * p.ldo + ncol[i]) = to_bf16x4(v);
+                } else if constexpr (EPI == EPI_ADD2) {
+                    v += aux[jj][i];
+                    if (ok) {
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.out_t) + mr * p.ldo + ncol[i]) = to_bf16x4(v);
+                        *reinterpret_cast<f32x4*>(p.out_f + mr * p.ldof + ncol[i]) = v;
+                    }
+                } else if constexpr (EPI == EPI_RESID) {
+                    if (p.gate) v *= gate4[i];
+                    if (ok && keep[jj]) *reinterpret_cast<f32x4*>(p.out_f + mr * p.ldof + ncol[i]) = aux[jj][i] + v;
+                }
+            });
         });
     });
 }
@@ -181,12 +302,15 @@ bool gemm_fast_supported(const GemmParams& p, int precision, int mode, int epi) 
     if (p.lda & 7) return false;
     if (mode == GEMM_DENSE) {
         if (p.K <= 0 || p.K % 64 != 0 || (p.ldw & 7)) return false;
-        return epi >= EPI_STORE_T && epi <= EPI_ROPE_T;
+        if (p.N % 4 != 0) return false;
+        if (epi == EPI_ROPE_T && (p.rope_inner % 64 != 0 || p.N % 64 != 0)) return false;
+        if (epi == EPI_RESID && p.gate && p.gate_bstride != 0) return false;
+        return epi >= EPI_STORE_T && epi <= EPI_GATE_T;
     }
     if (mode == GEMM_CONV31) {
         if (p.conv_win <= 0 || p.conv_win % 64 != 0 || p.N % 64 != 0 || p.conv_cg <= 0 || (p.conv_cg & 7)) return false;
         if (p.rows_per_batch <= 0 || p.M % p.rows_per_batch != 0) return false;
-        return epi == EPI_STORE_T || epi == EPI_RESID;
+        return epi == EPI_STORE_T || epi == EPI_GATE_T;
     }
     return false;
 }
@@ -194,7 +318,7 @@ bool gemm_fast_supported(const GemmParams& p, int precision, int mode, int epi) 
 int launch_gemm_fast(const GemmParams& p, int mode, int epi, hipStream_t stream) {
     if (mode == GEMM_CONV31) {
         if (epi == EPI_STORE_T) return launch_fast<64, 32, GEMM_CONV31, EPI_STORE_T>(p, stream);
-        if (epi == EPI_RESID) return launch_fast<64, 32, GEMM_CONV31, EPI_RESID>(p, stream);
+        if (epi == EPI_GATE_T) return launch_fast<64, 32, GEMM_CONV31, EPI_GATE_T>(p, stream);
         return f5_fail(F5_EINVAL, "gemm_fast(conv31): unsupported epilogue %d", epi);
     }
     const bool wide = p.N % 256 == 0;
@@ -207,6 +331,7 @@ int launch_gemm_fast(const GemmParams& p, int mode, int epi, hipStream_t stream)
         F5_FAST_CASE(EPI_RESID)
         F5_FAST_CASE(EPI_ADD2)
         F5_FAST_CASE(EPI_ROPE_T)
+        F5_FAST_CASE(EPI_GATE_T)
     }
 #undef F5_FAST_CASE
     return f5_fail(F5_EINVAL, "gemm_fast: unsupported epilogue %d", epi);

@@ -13,6 +13,9 @@ bool attention_fast_supported(int precision, int N, int H);
 // out[r][c] = LN(x[r][:])[c] * (add_one + mul[b(r)][c]) + add[b(r)][c]; b(r) = r / rows_per_batch; eps 1e-6
 int launch_layernorm(int precision_out /*F5_PREC_* of `out`*/, const float* x, int ldx, int rows, int dim, const float* mul,
                      const float* add, int mod_bstride, int rows_per_batch, int add_one, void* out, int ldo, hipStream_t stream);
+// same with the fp32 residual add fused in: x[r] += y[r] (y in the activation dtype, may be null) is written back first
+int launch_layernorm_add(int precision_out, float* x, int ldx, int rows, int dim, const void* y, int ldy, const float* mul, const float* add,
+                         int mod_bstride, int rows_per_batch, int add_one, void* out, int ldo, hipStream_t stream);
 // depthwise Conv1d(k=7, pad=3) along the sequence (+bias) then LayerNorm(eps 1e-6, affine) -> activation dtype
 // x f32 [B*N, C]; wt f32 [7][C] (tap-major); out [B*N, C]
 int launch_dwconv7_ln(int precision_out, const float* x, int B, int N, int C, const float* wt, const float* cbias, const float* ln_w,

@@ -64,7 +64,7 @@ struct f5_plan_s {
     float *xres = nullptr, *base = nullptr, *vout = nullptr, *mod = nullptr, *temb = nullptr, *tsin = nullptr, *thid = nullptr;
     float *tvals = nullptr, *coefs = nullptr, *te[2] = {nullptr, nullptr}, *grn_scratch = nullptr, *traj = nullptr, *xmid = nullptr;
     float *cond_in = nullptr, *rope = nullptr, *tap_scratch = nullptr;
-    void *hT = nullptr, *cT = nullptr, *qkv = nullptr, *ffh = nullptr, *abase = nullptr, *xin = nullptr, *teT = nullptr, *te_h = nullptr;
+    void *hT = nullptr, *cT = nullptr, *yT = nullptr, *qkv = nullptr, *ffh = nullptr, *abase = nullptr, *xin = nullptr, *teT = nullptr, *te_h = nullptr;
     uint8_t *filler = nullptr, *mask = nullptr;
     int32_t *text_in = nullptr, *lens_in = nullptr, *dur_in = nullptr;
     int rope_n = 0;
@@ -342,6 +342,7 @@ extern "C" int f5_plan_create(f5_model_t m, int max_batch, int max_seq, int max_
         if ((rc = A.alloc_t(&p->vout, rows * MELP))) break;
         if ((rc = A.alloc(&p->hT, rows * D * es))) break;
         if ((rc = A.alloc(&p->cT, rows * std::max(D, inner) * es))) break;
+        if ((rc = A.alloc(&p->yT, rows * D * es))) break;
         if ((rc = A.alloc(&p->qkv, rows * 3 * inner * es))) break;
         if ((rc = A.alloc(&p->ffh, rows * ff * es))) break;
         if ((rc = A.alloc(&p->abase, rows * (MELP + td) * es))) break;
@@ -521,25 +522,24 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
     g.a_row_mod = xrows < rows ? xrows : 0;
     g.addend = p->base; g.ldadd = D; g.out_t = p->hT; g.ldo = D; g.out_f = p->xres; g.ldof = D;
     F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_ADD2, st));
+    // x_res = h + mish(conv(mish(conv(h)))): the second conv only STORES its branch (activation dtype); every fp32 residual
+    // add of the network is fused into the LayerNorm pass that follows it (coalesced streaming RMW, store-only GEMM epilogues)
     for (int li = 0; li < 2; ++li) {
         g = gp_zero();
         g.A = li == 0 ? p->hT : p->cT; g.lda = D; g.W = m->w_conv[li]; g.M = rows; g.N = D; g.K = 31 * m->conv_win;
         g.bias = m->b_conv[li]; g.act = ACT_MISH; g.rows_per_batch = N; g.conv_cg = m->conv_cg; g.conv_win = m->conv_win;
-        if (li == 0) {
-            g.out_t = p->cT; g.ldo = D;
-            F5_TRY(run_gemm(p, g, GEMM_CONV31, EPI_STORE_T, st));
-        } else {
-            g.out_f = p->xres; g.ldof = D;
-            F5_TRY(run_gemm(p, g, GEMM_CONV31, EPI_RESID, st));
-        }
+        g.out_t = li == 0 ? p->cT : p->yT; g.ldo = D;
+        F5_TRY(run_gemm(p, g, GEMM_CONV31, li == 0 ? EPI_STORE_T : EPI_GATE_T, st));
     }
-    F5_TRY(tap_f32(p, "input_embed", p->xres, D, rows, D, st));
 
     for (int l = 0; l < c.depth; ++l) {
         const BlockW& b = m->blocks[l];
         const float* ml = modp + (size_t)l * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp (modules.py:312)
         const std::string tn = "blk" + std::to_string(l);
-        F5_TRY(launch_layernorm(P, p->xres, D, rows, D, ml + D, ml, mod_bstride, N, 1, p->hT, D, st));
+        // x += (conv branch | previous block's gated FF output); n1 = LN(x) * (1 + scale_msa) + shift_msa
+        F5_TRY(launch_layernorm_add(P, p->xres, D, rows, D, p->yT, D, ml + D, ml, mod_bstride, N, 1, p->hT, D, st));
+        if (l == 0) F5_TRY(tap_f32(p, "input_embed", p->xres, D, rows, D, st));
+        if (l > 0) F5_TRY(tap_f32(p, "blk" + std::to_string(l - 1) + ".out", p->xres, D, rows, D, st));
         F5_TRY(tap_t(p, tn + ".n1", p->hT, D, rows, D, st));
         g = gp_zero();
         g.A = p->hT; g.lda = D; g.W = b.w_qkv; g.ldw = D; g.M = rows; g.N = 3 * inner; g.K = D;
@@ -557,24 +557,27 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
             g.bias = b.b_o; g.out_f = d; g.ldof = D;
             F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_STORE_F32, st));
         }
+        // y = gate_msa * to_out(attn), 0 on padded query rows (modules.py:499-501, 635)
         g = gp_zero();
         g.A = p->cT; g.lda = inner; g.W = b.w_o; g.ldw = inner; g.M = rows; g.N = D; g.K = inner;
-        g.bias = b.b_o; g.out_f = p->xres; g.ldof = D; g.gate = ml + 2 * D; g.gate_bstride = mod_bstride; g.rows_per_batch = N;
+        g.bias = b.b_o; g.out_t = p->yT; g.ldo = D; g.gate = ml + 2 * D; g.gate_bstride = mod_bstride; g.rows_per_batch = N;
         g.rowmask = mask;
-        F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_RESID, st));
-        F5_TRY(launch_layernorm(P, p->xres, D, rows, D, ml + 4 * D, ml + 3 * D, mod_bstride, N, 1, p->hT, D, st));
+        F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_GATE_T, st));
+        // x += y; n2 = LN(x) * (1 + scale_mlp) + shift_mlp
+        F5_TRY(launch_layernorm_add(P, p->xres, D, rows, D, p->yT, D, ml + 4 * D, ml + 3 * D, mod_bstride, N, 1, p->hT, D, st));
         g = gp_zero();
         g.A = p->hT; g.lda = D; g.W = b.w_ff1; g.ldw = D; g.M = rows; g.N = ff; g.K = D;
         g.bias = b.b_ff1; g.act = ACT_GELU_TANH; g.out_t = p->ffh; g.ldo = ff;
         F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_STORE_T, st));
+        // y = gate_mlp * ff(n2)  (modules.py:639)
         g = gp_zero();
         g.A = p->ffh; g.lda = ff; g.W = b.w_ff2; g.ldw = ff; g.M = rows; g.N = D; g.K = ff;
-        g.bias = b.b_ff2; g.out_f = p->xres; g.ldof = D; g.gate = ml + 5 * D; g.gate_bstride = mod_bstride; g.rows_per_batch = N;
-        F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_RESID, st));
-        F5_TRY(tap_f32(p, tn + ".out", p->xres, D, rows, D, st));
+        g.bias = b.b_ff2; g.out_t = p->yT; g.ldo = D; g.gate = ml + 5 * D; g.gate_bstride = mod_bstride; g.rows_per_batch = N;
+        F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_GATE_T, st));
     }
     const float* mf = modp + (size_t)c.depth * 6 * D;  // final AdaLN: (scale, shift) (modules.py:333)
-    F5_TRY(launch_layernorm(P, p->xres, D, rows, D, mf, mf + D, mod_bstride, N, 1, p->hT, D, st));
+    F5_TRY(launch_layernorm_add(P, p->xres, D, rows, D, p->yT, D, mf, mf + D, mod_bstride, N, 1, p->hT, D, st));
+    F5_TRY(tap_f32(p, "blk" + std::to_string(c.depth - 1) + ".out", p->xres, D, rows, D, st));
     F5_TRY(tap_t(p, "final_norm", p->hT, D, rows, D, st));
     g = gp_zero();
     g.A = p->hT; g.lda = D; g.W = m->w_out; g.ldw = D; g.M = rows; g.N = MELP; g.K = D;

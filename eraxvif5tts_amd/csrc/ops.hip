@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void fill_random_f32_kernel(float* dst, size_t
 
 // Times `iters` back-to-back launches of ONE GEMM kernel (bf16, the epilogue/shape of the DiT call site `site`) with HIP
 // events on `stream`; *ms_avg = average device time of one launch.  site: 0 = fused QKV projection + RoPE (N = 3*inner),
-// 1 = FF1 + GELU-tanh, 2 = FF2 + gated residual, 3 = attention out-projection + gated residual.
+// 1 = FF1 + GELU-tanh, 2 = FF2 + gate, 3 = attention out-projection + gate (store-only residual branches).
 extern "C" int f5_bench_gemm_site(int kernel, int site, int rows, int seq, int dim, int heads, int ff_inner, int iters, float* ms_avg,
                                   f5_stream_t stream) {
     F5_TRY(f5_check_device());
@@ -145,8 +145,8 @@ extern "C" int f5_bench_gemm_site(int kernel, int site, int rows, int seq, int d
     switch (site) {
         case 0: N = 3 * inner; K = dim; epi = EPI_ROPE_T; break;
         case 1: N = ff_inner; K = dim; epi = EPI_STORE_T; break;
-        case 2: N = dim; K = ff_inner; epi = EPI_RESID; break;
-        case 3: N = dim; K = inner; epi = EPI_RESID; break;
+        case 2: N = dim; K = ff_inner; epi = EPI_GATE_T; break;
+        case 3: N = dim; K = inner; epi = EPI_GATE_T; break;
         default: return f5_fail(F5_EINVAL, "bad site");
     }
     const size_t Mp = (size_t)round_up(rows, 256);
@@ -173,7 +173,7 @@ extern "C" int f5_bench_gemm_site(int kernel, int site, int rows, int seq, int d
         g.A = A; g.lda = K; g.W = W; g.ldw = K; g.M = rows; g.N = N; g.K = K; g.bias = bias; g.rows_per_batch = seq;
         if (epi == EPI_ROPE_T) { g.out_t = out; g.ldo = N; g.rope = rope; g.rope_inner = inner; g.rope_heads = 1; }
         if (epi == EPI_STORE_T) { g.out_t = out; g.ldo = N; g.act = ACT_GELU_TANH; }
-        if (epi == EPI_RESID) { g.out_f = resid; g.ldof = dim; g.gate = gate; g.gate_bstride = 0; }
+        if (epi == EPI_GATE_T) { g.out_t = out; g.ldo = N; g.gate = gate; g.gate_bstride = 0; }
         if (kernel == 1 && !gemm_fast_supported(g, F5_PREC_BF16, GEMM_DENSE, epi)) { rc = f5_fail(F5_ENOTSUP, "tuned kernel cannot run this site"); break; }
         if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { rc = f5_fail(F5_EHIP, "hipEventCreate failed"); break; }
         for (int i = 0; i < 2 && rc == 0; ++i) rc = launch_gemm(g, F5_PREC_BF16, GEMM_DENSE, epi, kernel, st);
