@@ -2,12 +2,13 @@
 //
 // Structure (MI355X-first, see /opt/skills/guides/cdna_hip_programming.md section 5):
 //   * 256-token x BN-feature output tile per 512-thread workgroup (8 wavefronts, one workgroup per CU, 2 waves per SIMD),
-//     K-step 64; v_mfma_f32_16x16x32_bf16 with the weight rows on the MFMA row index, so each lane finishes with 4
+//     v_mfma_f32_16x16x32_bf16 with the weight rows on the MFMA row index, so each lane finishes with 4
 //     consecutive output features of one token (vector stores, lane-local RoPE pairs);
-//   * both operand tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (LDS-DMA, no VGPR staging), double-buffered:
-//     the DMA of K-step t+1 is in flight while the MFMAs of K-step t run; one s_barrier per K-step;
-//   * LDS image is lane-linear (a DMA instruction writes 8 rows x 128 B); bank conflicts of the ds_read_b128 fragment
-//     reads are removed by an XOR swizzle applied on the *source* address and on the read (16-byte chunk ^= (row>>1)&7);
+//   * both operand tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (LDS-DMA, no VGPR staging) through a 4-slot ring of
+//     32-deep K-steps: three K-steps are in flight while one is consumed (counted s_waitcnt vmcnt, never 0 in the loop),
+//     one raw s_barrier per K-step;
+//   * LDS image is lane-linear (a DMA instruction writes 16 rows x 64 B); bank conflicts of the ds_read_b128 fragment
+//     reads are removed by an XOR swizzle applied on the *source* address and on the read (16-byte chunk ^= (-(row>>2))&3);
 //   * blockIdx -> tile mapping is XCD-aware (each XCD's L2 sees a contiguous band of token tiles x all feature tiles);
 //   * GEMM_CONV31: the same engine as an implicit GEMM for the grouped Conv1d(k=31): K-steps walk (tap, 64 channels),
 //     the DMA source row is shifted by tap-15 and rows outside the utterance read a zero page.
@@ -49,15 +50,16 @@ __device__ __forceinline__ void dma16(const void* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
-template <int BN, int WM, int MODE, int EPI>
+template <int BN, int WM, int MODE, int EPI, int VAR>
 __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(GemmParams p, int tiles_n, int nblocks) {
-    constexpr int BM = 256, BK = 64, WN = 64;
+    constexpr int BM = 256, BK = 32, WN = 64, NSTAGE = 4;
     constexpr int WAVES_N = BN / WN;
     constexpr int MI = WM / 16, NI = WN / 16;
     constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
-    constexpr int WJ = BN / 64;  // weight DMA instructions per wave per K-step
+    constexpr int WJ = BN >= 256 ? 2 : 1;  // weight DMA pieces (16 rows x 64 B) per wave per K-step (BN = 64: waves 4-7 duplicate 0-3)
+    constexpr int PPW = 2 + WJ;            // DMA pieces per wave per K-step (vmcnt bookkeeping)
     static_assert((BM / WM) * WAVES_N == 8, "8 waves");
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -72,74 +74,73 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
     const bf16_t* W = reinterpret_cast<const bf16_t*>(p.W);
 
-    // ---- DMA source bookkeeping: 4 A pieces + WJ W pieces per wave per K-step, each piece = 8 rows x 128 B
-    const int prow = lane >> 3, pchunk = lane & 7;
-    const bf16_t* a_src[4];
-    int a_pos[4];
-    bool a_ok[4];
+    // ---- DMA source bookkeeping: 2 A pieces + WJ W pieces per wave per K-step, each piece = 16 rows x 64 B
+    const int prow = lane >> 2, pchunk = lane & 3;
+    const int plc = pchunk ^ ((0 - (prow >> 2)) & 3);  // logical 16-byte chunk stored at this physical slot (piece rows are 16-aligned)
+    const bf16_t* a_src[2];
+    int a_pos[2];
+    bool a_ok[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int ra = (wave * 4 + j) * 8 + prow;
-        const int lc = pchunk ^ ((ra >> 1) & 7);  // logical 16-byte chunk stored at this physical slot
-        int gm = m0 + ra;
+    for (int j = 0; j < 2; ++j) {
+        int gm = m0 + (wave * 2 + j) * 16 + prow;
         a_ok[j] = gm < p.M;
         if (gm >= p.M) gm = p.M - 1;
+        a_pos[j] = 0;
         if constexpr (MODE == GEMM_DENSE) {
             if (p.a_row_mod > 0) gm %= p.a_row_mod;
-            a_src[j] = A + (size_t)gm * p.lda + lc * 8;
-            a_pos[j] = 0;
         } else {
             a_pos[j] = gm % p.rows_per_batch;
-            a_src[j] = A + (size_t)gm * p.lda + lc * 8;
         }
+        a_src[j] = A + (size_t)gm * p.lda + plc * 8;
     }
     const bf16_t* w_src[WJ];
-    int w_lc[WJ];
+    int w_piece[WJ];
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
-        const int rw = (wave * WJ + j) * 8 + prow;
-        w_lc[j] = pchunk ^ ((rw >> 1) & 7);
-        int gn = n0 + rw;
+        w_piece[j] = (wave * WJ + j) % (BN / 16);
+        int gn = n0 + w_piece[j] * 16 + prow;
         if (gn >= p.N) gn = p.N - 1;
         if constexpr (MODE == GEMM_DENSE)
-            w_src[j] = W + (size_t)gn * p.ldw + w_lc[j] * 8;
+            w_src[j] = W + (size_t)gn * p.ldw + plc * 8;
         else
-            w_src[j] = W + (size_t)gn * p.conv_win + w_lc[j] * 8;
+            w_src[j] = W + (size_t)gn * p.conv_win + plc * 8;
     }
     const int cslices = MODE == GEMM_CONV31 ? p.conv_win / BK : 1;
     const int nk = MODE == GEMM_CONV31 ? 31 * cslices : p.K / BK;
     const int win0 = MODE == GEMM_CONV31 ? (n0 / p.conv_cg) * p.conv_cg : 0;
     const int L = p.rows_per_batch;
 
-    auto issue = [&](int kt, int stage) {
-        char* sbase = smem + stage * STAGE;
+    // piece ids of one K-step for this wave: 0,1 = activation pieces, 2.. = weight pieces
+    auto issue_piece = [&](int kt, int piece) {
+        char* sbase = smem + (kt & (NSTAGE - 1)) * STAGE;
         if constexpr (MODE == GEMM_DENSE) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dma16(a_src[j] + (size_t)kt * BK, sbase + (wave * 4 + j) * 1024);
-#pragma unroll
-            for (int j = 0; j < WJ; ++j) dma16(w_src[j] + (size_t)kt * BK, sbase + A_BYTES + (wave * WJ + j) * 1024);
+            if (piece < 2)
+                dma16(a_src[piece] + (size_t)kt * BK, sbase + (wave * 2 + piece) * 1024);
+            else
+                dma16(w_src[piece - 2] + (size_t)kt * BK, sbase + A_BYTES + w_piece[piece - 2] * 1024);
         } else {
             const int tap = kt / cslices, sl = kt - tap * cslices;
             const int ch0 = win0 + sl * BK;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int sp = a_pos[j] + tap - 15;
-                const int lc = pchunk ^ ((((wave * 4 + j) * 8 + prow) >> 1) & 7);
-                const bool ok = a_ok[j] && sp >= 0 && sp < L && (ch0 + lc * 8) < p.N;
-                const void* src = ok ? (const void*)(a_src[j] + (ptrdiff_t)(tap - 15) * p.lda + ch0) : (const void*)g_zero_page;
-                dma16(src, sbase + (wave * 4 + j) * 1024);
+            if (piece < 2) {
+                const int sp = a_pos[piece] + tap - 15;  // Conv1d(padding=15): zero outside [0, L) of this utterance
+                const bool ok = a_ok[piece] && sp >= 0 && sp < L && (ch0 + plc * 8) < p.N;
+                const void* src = ok ? (const void*)(a_src[piece] + (ptrdiff_t)(tap - 15) * p.lda + ch0) : (const void*)g_zero_page;
+                dma16(src, sbase + (wave * 2 + piece) * 1024);
+            } else {
+                dma16(w_src[piece - 2] + (size_t)tap * p.N * p.conv_win + sl * BK, sbase + A_BYTES + w_piece[piece - 2] * 1024);
             }
-#pragma unroll
-            for (int j = 0; j < WJ; ++j)
-                dma16(w_src[j] + (size_t)tap * p.N * p.conv_win + sl * BK, sbase + A_BYTES + (wave * WJ + j) * 1024);
         }
+    };
+    auto issue = [&](int kt) {
+#pragma unroll
+        for (int pc = 0; pc < PPW; ++pc) issue_piece(kt, pc);
     };
 
     // ---- fragment read offsets (bytes inside a stage)
     const int fr = lane & 15, fq = lane >> 4;
-    const int c0 = (fq ^ (fr >> 1)) * 16;
-    const int a_off0 = (wm * WM + fr) * 128 + c0, a_off1 = (wm * WM + fr) * 128 + (c0 ^ 64);
-    const int w_off0 = A_BYTES + (wn * WN + fr) * 128 + c0, w_off1 = A_BYTES + (wn * WN + fr) * 128 + (c0 ^ 64);
+    const int c0 = (fq ^ ((0 - (fr >> 2)) & 3)) * 16;
+    const int a_off = (wm * WM + fr) * 64 + c0;
+    const int w_off = A_BYTES + (wn * WN + fr) * 64 + c0;
 
     // ---- epilogue operands that do not depend on the token are fetched now, so their latency hides under the main loop
     int ncol[NI];
@@ -169,28 +170,116 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
 #pragma unroll
         for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    auto read_frags = [&](int kt, bf16x8 (&wf)[NI], bf16x8 (&af)[MI]) {
+        const char* sb = smem + (kt & (NSTAGE - 1)) * STAGE;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + w_off + i * 1024);
+#pragma unroll
+        for (int j = 0; j < MI; ++j) af[j] = *reinterpret_cast<const bf16x8*>(sb + a_off + j * 1024);
+    };
+    auto mma = [&](const bf16x8 (&wf)[NI], const bf16x8 (&af)[MI]) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    };
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int stage = kt & 1;
-        if (kt + 1 < nk) issue(kt + 1, stage ^ 1);
-        const char* sb = smem + stage * STAGE;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+    if constexpr (VAR == 0) {
+        // ---- ring, fragments read and consumed in the same K-step: slot t&3 is consumed while K-steps t+1..t+3 are in flight
+        for (int kt = 0; kt < nk; ++kt) {
+            // my own pieces of K-step kt have landed once at most the pieces of the younger K-steps are still outstanding
+            if (kt + 2 < nk)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+            else if (kt + 1 < nk)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // every wave's pieces of K-step kt have landed AND every wave has finished reading slot (kt-1)&3
+            __builtin_amdgcn_s_barrier();
+            if (kt + 3 < nk) issue(kt + 3);  // refills slot (kt-1)&3
             bf16x8 wf[NI], af[MI];
+            read_frags(kt, wf, af);
+            mma(wf, af);
+        }
+    } else if constexpr (VAR == 1) {
+        // ---- ring + staggered wave groups (the two waves that share a SIMD never run the same phase together):
+        //   every wave alternates  P_k: {refill slot (k-1)&3 by DMA, ds_read the fragments of K-step k, counted vmcnt for
+        //   K-step k+1}  |barrier|  C_k: {32 MFMAs}  |barrier| ...; waves 4-7 run one barrier interval behind waves 0-3,
+        //   so in every interval one group feeds the matrix pipe while its SIMD partners do their LDS/DMA work.
+        const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+        if (nk > 2)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else if (nk > 1)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // K-step 0 has landed for every wave
+        if (late) __builtin_amdgcn_s_barrier();
+        bf16x8 wf[NI], af[MI];
+        for (int kt = 0; kt < nk; ++kt) {
+            // -- P_kt.  Slot (kt-1)&3 is free: both groups retired their reads of it (lgkmcnt(0) below) at least one barrier ago.
+            if (kt + 3 < nk) issue(kt + 3);
+            read_frags(kt, wf, af);
+            // my pieces of K-step kt+1 must have landed before the barrier that precedes anybody's P_{kt+1}
+            if (kt + 3 < nk)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+            else if (kt + 2 < nk)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // -- C_kt
+            __builtin_amdgcn_s_setprio(1);
+            mma(wf, af);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (!late) __builtin_amdgcn_s_barrier();  // same barrier count for both groups
+    } else {
+        // ---- staggered wave groups, DMA issue moved from the load phase into the MFMA phase: the LDS-DMA pieces of
+        //      K-step kt+3 are issued between groups of MFMAs (they do not use the matrix pipe), which shortens the load
+        //      phase P_k to {12 ds_reads + waits} so both barrier intervals are about one MFMA cluster long.
+        const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+        if (nk > 2)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else if (nk > 1)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (late) __builtin_amdgcn_s_barrier();
+        bf16x8 wf[NI], af[MI];
+        for (int kt = 0; kt < nk; ++kt) {
+            // -- P_kt: fragments of K-step kt; my pieces of K-step kt+1 landed (kt+2 may be outstanding, kt+3 is issued in C_kt)
+            read_frags(kt, wf, af);
+            if (kt + 2 < nk)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // -- C_kt: 32 MFMAs with the DMA pieces of K-step kt+3 (slot (kt-1)&3, retired two barriers ago) in between
+            __builtin_amdgcn_s_setprio(1);
+            const bool more = kt + 3 < nk;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + (ks ? w_off1 : w_off0) + i * 2048);
-#pragma unroll
-            for (int j = 0; j < MI; ++j) af[j] = *reinterpret_cast<const bf16x8*>(sb + (ks ? a_off1 : a_off0) + j * 2048);
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
+            for (int i = 0; i < NI; ++i) {
 #pragma unroll
                 for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+                if (i < PPW && more) issue_piece(kt + 3, i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next stage landed (this wave's pieces) ...
-        __builtin_amdgcn_s_barrier();                       // ... and every wave is done reading the current one
+        if (!late) __builtin_amdgcn_s_barrier();
     }
 
     // ---------------------------------------------------------------- epilogue (store-only wherever the call site allows)
@@ -289,10 +378,17 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
     });
 }
 
+int g_gemm_variant = 1;  // tuning knob (f5_tuning_set("gemm_variant", v)): 0 = ring, 1 = ring + staggered wave groups, 2 = staggered + DMA issue inside the MFMA phase
+
 template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmParams& p, hipStream_t stream) {
     const int tiles_m = cdiv(p.M, 256), tiles_n = cdiv(p.N, BN);
     const int nblocks = tiles_m * tiles_n;
-    hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI>), dim3(nblocks), dim3(512), 0, stream, p, tiles_n, nblocks);
+    if (BN == 256 && g_gemm_variant == 1)
+        hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, (BN == 256 ? 1 : 0)>), dim3(nblocks), dim3(512), 0, stream, p, tiles_n, nblocks);
+    else if (BN == 256 && g_gemm_variant == 2)
+        hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, (BN == 256 ? 2 : 0)>), dim3(nblocks), dim3(512), 0, stream, p, tiles_n, nblocks);
+    else
+        hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 0>), dim3(nblocks), dim3(512), 0, stream, p, tiles_n, nblocks);
     F5_LAUNCH_CHECK();
     return 0;
 }
@@ -301,14 +397,14 @@ bool gemm_fast_supported(const GemmParams& p, int precision, int mode, int epi) 
     if (precision != F5_PREC_BF16 || p.M <= 0 || p.N <= 0) return false;
     if (p.lda & 7) return false;
     if (mode == GEMM_DENSE) {
-        if (p.K <= 0 || p.K % 64 != 0 || (p.ldw & 7)) return false;
+        if (p.K <= 0 || p.K % 32 != 0 || (p.ldw & 7)) return false;
         if (p.N % 4 != 0) return false;
         if (epi == EPI_ROPE_T && (p.rope_inner % 64 != 0 || p.N % 64 != 0)) return false;
         if (epi == EPI_RESID && p.gate && p.gate_bstride != 0) return false;
         return epi >= EPI_STORE_T && epi <= EPI_GATE_T;
     }
     if (mode == GEMM_CONV31) {
-        if (p.conv_win <= 0 || p.conv_win % 64 != 0 || p.N % 64 != 0 || p.conv_cg <= 0 || (p.conv_cg & 7)) return false;
+        if (p.conv_win <= 0 || p.conv_win % 32 != 0 || p.N % 64 != 0 || p.conv_cg <= 0 || (p.conv_cg & 7)) return false;
         if (p.rows_per_batch <= 0 || p.M % p.rows_per_batch != 0) return false;
         return epi == EPI_STORE_T || epi == EPI_GATE_T;
     }

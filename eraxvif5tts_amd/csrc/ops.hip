@@ -224,3 +224,13 @@ extern "C" int f5_bench_attention(int kernel, int B, int N, int H, int iters, fl
     if (e1) (void)hipEventDestroy(e1);
     return sync_and_release(a, st, rc);
 }
+
+extern int g_gemm_variant;
+extern "C" int f5_tuning_set(const char* key, int value) {
+    if (!key) return f5_fail(F5_EINVAL, "null key");
+    if (strcmp(key, "gemm_variant") == 0) {
+        g_gemm_variant = value;
+        return 0;
+    }
+    return f5_fail(F5_EINVAL, "unknown tuning key '%s'", key);
+}

@@ -150,6 +150,8 @@ int f5_op_conv_pos_embed(int precision, int B, int N, int dim, const float* x, c
 int f5_bench_gemm_site(int kernel, int site, int rows, int seq, int dim, int heads, int ff_inner, int iters, float* ms_avg,
                        f5_stream_t stream);
 int f5_bench_attention(int kernel, int B, int N, int H, int iters, float* ms_avg, f5_stream_t stream);
+/* process-wide kernel tuning knobs for A/B measurements ("gemm_variant": main-loop schedule of the tuned GEMM) */
+int f5_tuning_set(const char* key, int value);
 
 /* ------------------------------------------------------------------ Vocos vocoder (plug point B) */
 typedef struct f5_vocos_config {
