@@ -1,0 +1,205 @@
+"""F5TTSWrapper: preprocess one reference voice once, synthesize many texts -- the reference's inference facade
+(``f5_tts/infer/f5tts_wrapper.py:28-621``) over the MI355X HIP backbone, sampler and vocoder.
+
+Same constructor kwargs/defaults (:34-52), ``preprocess_reference(ref_audio_path, ref_text, clip_short)`` (:256-354),
+``generate(text, output_path, nfe_step, cfg_strength, sway_sampling_coef, speed, fix_duration, cross_fade_duration,
+use_duration_predictor, return_numpy, return_spectrogram)`` (:408-607), ``get_current_audio_length`` (:618-621), the same
+stored fields, error types and the three return shapes.
+
+Differences forced by the offline, ROCm-only image (each raises instead of silently approximating):
+  * no Whisper ASR is initialised (reference :100 downloads openai/whisper-large-v3-turbo): ``ref_text`` must be given;
+  * checkpoints and the Vocos weights must be local files (reference :125 / utils_infer.py:110-112 fetch from the hub);
+  * ``device`` must be a ROCm GPU: the backbone has no CPU path.
+The optional conv duration predictor (:381-406) is a "next" row of the scope table and is reported as absent, which is the
+reference's own fallback branch (:166-168).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+import yaml
+
+from ..model import CFM
+from ..model import backbones as _backbones
+from ..model.utils import convert_char_to_pinyin, get_tokenizer
+from . import audio as _audio
+from .utils_infer import DEFAULT_VOCAB, chunk_text, cross_fade_concat, load_checkpoint, load_vocoder
+
+_CONFIG_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs")
+
+
+class F5TTSWrapper:
+    """A wrapper class for F5-TTS that preprocesses reference audio once and allows for repeated TTS generation."""
+
+    def __init__(self, model_name: str = "F5TTS_v1_Base", ckpt_path: Optional[str] = None, vocab_file: Optional[str] = None,
+                 vocoder_name: str = "vocos", use_local_vocoder: bool = False, vocoder_path: Optional[str] = None,
+                 device: Optional[str] = None, hf_cache_dir: Optional[str] = None, target_sample_rate: int = 24000,
+                 n_mel_channels: int = 100, hop_length: int = 256, win_length: int = 1024, n_fft: int = 1024,
+                 ode_method: str = "euler", use_ema: bool = True, use_duration_predictor: bool = False,
+                 vocoder=None, precision: Optional[str] = None):
+        if device is None:
+            device = "cuda" if torch.cuda.is_available() else "cpu"
+        self.device = device
+        self.target_sample_rate, self.n_mel_channels = target_sample_rate, n_mel_channels
+        self.hop_length, self.win_length, self.n_fft = hop_length, win_length, n_fft
+        self.mel_spec_type = vocoder_name
+        self.ode_method = ode_method
+        self.use_duration_predictor = use_duration_predictor
+
+        # model configuration: a bundled config name, or (reference :128-131) a YAML path when "custom" is in the name
+        config_path = os.path.join(_CONFIG_DIR, f"{model_name}.yaml") if "custom" not in model_name.lower() else model_name
+        with open(config_path, "r") as f:
+            model_cfg = yaml.safe_load(f)
+        model_cls = getattr(_backbones, model_cfg["model"]["backbone"], None)  # plug point A (reference :134)
+        if model_cls is None:
+            raise NotImplementedError(f"backbone {model_cfg['model']['backbone']} is not on the MI355X path (DiT only)")
+        model_arc = dict(model_cfg["model"]["arch"])
+        if precision is not None:
+            model_arc["precision"] = precision
+
+        if vocab_file is None:
+            vocab_file = DEFAULT_VOCAB
+        self.vocab_char_map, vocab_size = get_tokenizer(vocab_file, "custom")
+
+        self.model = CFM(
+            transformer=model_cls(**model_arc, text_num_embeds=vocab_size, mel_dim=n_mel_channels),
+            mel_spec_kwargs=dict(n_fft=n_fft, hop_length=hop_length, win_length=win_length, n_mel_channels=n_mel_channels,
+                                 target_sample_rate=target_sample_rate, mel_spec_type=vocoder_name),
+            odeint_kwargs=dict(method=ode_method),
+            vocab_char_map=self.vocab_char_map,
+        ).to(self.device)
+
+        if ckpt_path is None:
+            raise FileNotFoundError("ckpt_path is required: the reference's default (hf://SWivid/F5-TTS/...) is a network download")
+        self._load_checkpoint(self.model, ckpt_path, use_ema=use_ema)
+
+        self.has_duration_predictor = hasattr(self.model, "duration_predictor") and self.model.duration_predictor is not None
+        if self.use_duration_predictor and not self.has_duration_predictor:
+            print("Warning: Duration predictor requested but not found in model. Using fallback duration calculation.")
+            self.use_duration_predictor = False
+
+        if vocoder is not None:  # plug point B: any object with .decode(mel[b, 100, T])
+            self.vocoder = vocoder
+        else:
+            if vocoder_path is None:
+                vocoder_path = "../checkpoints/vocos-mel-24khz"
+            self.vocoder = load_vocoder(vocoder_name=vocoder_name, is_local=use_local_vocoder, local_path=vocoder_path,
+                                        device=self.device, hf_cache_dir=hf_cache_dir)
+
+        self.ref_audio_processed = None
+        self.ref_text = None
+        self.ref_audio_len = None
+        self.target_rms = 0.1
+        self.cross_fade_duration = 0.15
+        self.nfe_step = 32
+        self.cfg_strength = 2.0
+        self.sway_sampling_coef = -1.0
+        self.speed = 1.0
+        self.fix_duration = None
+
+    def _load_checkpoint(self, model, ckpt_path, dtype=None, use_ema=True):
+        return load_checkpoint(model, ckpt_path, self.device, dtype=dtype, use_ema=use_ema)
+
+    # ------------------------------------------------------------------ reference voice
+    def preprocess_reference(self, ref_audio_path: str, ref_text: str = "", clip_short: bool = True):
+        print("Converting audio...")
+        aseg = _audio.Segment.from_file(ref_audio_path)
+        if clip_short:
+            aseg = _audio.clip_reference(aseg)
+        aseg = self._remove_silence_edges(aseg)
+        aseg = aseg + aseg.silent_like(50)
+        if not ref_text.strip():
+            raise RuntimeError("No reference text provided: automatic transcription (Whisper) needs a network model download; pass ref_text")
+        print("Using custom reference text...")
+        if not ref_text.endswith(". ") and not ref_text.endswith("。"):
+            ref_text += " " if ref_text.endswith(".") else ". "
+        print("\nReference text:", ref_text)
+
+        audio, sr = _audio.segment_to_float(aseg), aseg.frame_rate
+        if audio.shape[0] > 1:
+            audio = torch.mean(audio, dim=0, keepdim=True)
+        rms = torch.sqrt(torch.mean(torch.square(audio)))
+        if rms < self.target_rms:  # boosted only when quieter than the target (reference :334-336)
+            audio = audio * self.target_rms / rms
+        if sr != self.target_sample_rate:
+            audio = _audio.resample(audio, sr, self.target_sample_rate)
+        audio = audio.to(self.device)
+        self.ref_audio_processed = audio
+        self.ref_text = ref_text
+        self.ref_audio_len = audio.shape[-1] // self.hop_length
+        return audio, ref_text
+
+    def _remove_silence_edges(self, audio, silence_threshold=-42):
+        return _audio.remove_silence_edges(audio, silence_threshold)
+
+    def calculate_duration_with_predictor(self, text_tokens, text_lengths, local_speed=1.0):
+        raise NotImplementedError("the optional duration predictor is not part of this build (scope table row f.2)")
+
+    # ------------------------------------------------------------------ synthesis
+    def generate(self, text: str, output_path: Optional[str] = None, nfe_step: Optional[int] = None, cfg_strength: Optional[float] = None,
+                 sway_sampling_coef: Optional[float] = None, speed: Optional[float] = None, fix_duration: Optional[float] = None,
+                 cross_fade_duration: Optional[float] = None, use_duration_predictor: Optional[bool] = None,
+                 return_numpy: bool = False, return_spectrogram: bool = False):
+        if self.ref_audio_processed is None or self.ref_text is None:
+            raise ValueError("Reference audio not preprocessed. Call preprocess_reference() first.")
+        nfe_step = nfe_step if nfe_step is not None else self.nfe_step
+        cfg_strength = cfg_strength if cfg_strength is not None else self.cfg_strength
+        sway_sampling_coef = sway_sampling_coef if sway_sampling_coef is not None else self.sway_sampling_coef
+        speed = speed if speed is not None else self.speed
+        fix_duration = fix_duration if fix_duration is not None else self.fix_duration
+        cross_fade_duration = cross_fade_duration if cross_fade_duration is not None else self.cross_fade_duration
+
+        audio_len = self.ref_audio_processed.shape[-1] / self.target_sample_rate
+        max_chars = int(len(self.ref_text.encode("utf-8")) / audio_len * (22 - audio_len))
+        text_batches = chunk_text(text, max_chars=max_chars)
+        for i, text_batch in enumerate(text_batches):
+            print(f"Text batch {i}: {text_batch}")
+        print("\n")
+
+        generated_waves, spectrograms = [], []
+        for text_batch in text_batches:
+            local_speed = 0.3 if len(text_batch.encode("utf-8")) < 10 else speed
+            final_text_list = convert_char_to_pinyin([self.ref_text + text_batch])
+            if fix_duration is not None:
+                duration = int(fix_duration * self.target_sample_rate / self.hop_length)
+                print(f"Using fixed duration: {fix_duration}s ({duration} frames)")
+            else:
+                ref_text_len, gen_text_len = len(self.ref_text.encode("utf-8")), len(text_batch.encode("utf-8"))
+                duration = self.ref_audio_len + int(self.ref_audio_len / ref_text_len * gen_text_len / local_speed)
+                print(f"Calculated duration based on text ratio: {duration} frames")
+            with torch.inference_mode():
+                generated, _ = self.model.sample(cond=self.ref_audio_processed, text=final_text_list, duration=duration, steps=nfe_step,
+                                                 cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef, return_trajectory=False)
+                generated = generated.to(torch.float32)[:, self.ref_audio_len:, :].permute(0, 2, 1)
+                generated_wave = self.vocoder.decode(generated)
+                rms = torch.sqrt(torch.mean(torch.square(self.ref_audio_processed)))  # of the stored, already boosted prompt (:529-531)
+                if rms < self.target_rms:
+                    generated_wave = generated_wave * rms / self.target_rms
+                generated_waves.append(generated_wave.squeeze().cpu().numpy())
+                if return_spectrogram or output_path is not None:
+                    spectrograms.append(generated.squeeze().cpu().numpy())
+
+        if not generated_waves:
+            raise RuntimeError("No audio generated")
+        final_wave = cross_fade_concat(generated_waves, cross_fade_duration, self.target_sample_rate)
+        combined_spectrogram = np.concatenate(spectrograms, axis=1) if spectrograms else None
+        if output_path is not None:
+            output_dir = os.path.dirname(output_path)
+            if output_dir and not os.path.exists(output_dir):
+                os.makedirs(output_dir)
+            _audio.write_wav(output_path, final_wave, self.target_sample_rate)
+            if return_spectrogram:
+                np.save(os.path.splitext(output_path)[0] + "_spec.npy", combined_spectrogram)  # matplotlib is not in the image
+            if not return_numpy:
+                return output_path
+        if return_spectrogram:
+            return final_wave, self.target_sample_rate, combined_spectrogram
+        return final_wave, self.target_sample_rate
+
+    def get_current_audio_length(self):
+        if self.ref_audio_processed is None:
+            return 0
+        return self.ref_audio_processed.shape[-1] / self.target_sample_rate

@@ -1,0 +1,130 @@
+"""Vocos vocoder (plug point B) and the F5TTSWrapper facade on the GPU, through the C ABI.
+
+Tolerances: the vocoder runs on the fp32-input MFMA (exact fp32 products, fp32 accumulation): rel-L2 <= 1e-4 against the
+CPU oracle (sum order + exp/sin/cos ulps); the ISTFT head alone <= 1e-5 against torch.istft."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from conftest import rel_l2
+from oracle import cpu_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    from eraxvif5tts_amd import _lib
+    _lib.require_gpu()
+
+
+def _vocos(V, **hp):
+    from eraxvif5tts_amd.vocos import Vocos
+    v = Vocos(**hp)
+    v.load_state_dict({k: t for k, t in V.items() if k in v.state_dict()}, strict=False)
+    return v.cuda()
+
+
+@pytest.mark.parametrize("B,T", [(1, 40), (2, 129), (3, 7)])
+def test_vocos_decode_matches_oracle(B, T):
+    V = cpu_ref.random_vocos_weights(seed=3)
+    voc = _vocos(V)
+    mel = torch.randn(B, 100, T, generator=torch.Generator().manual_seed(T)) * 2 - 3
+    ref = cpu_ref.vocos_decode(V, mel)
+    out = voc.decode(mel.cuda()).cpu()
+    assert out.shape == ref.shape == (B, (T - 1) * 256)
+    assert rel_l2(out, ref) < 1e-4
+
+
+def test_istft_head_matches_torch_istft_and_round_trips():
+    V = cpu_ref.random_vocos_weights(seed=4)
+    voc = _vocos(V)
+    g = torch.Generator().manual_seed(0)
+    # (1) random head activations vs torch.istft on the same spectrum
+    B, T = 2, 33
+    head = torch.cat([torch.randn(B, T, 513, generator=g) * 0.5, torch.randn(B, T, 513, generator=g) * 3.0], dim=-1)
+    mag = torch.exp(head[..., :513]).clamp(max=1e2).transpose(1, 2)
+    ph = head[..., 513:].transpose(1, 2)
+    spec = torch.complex(mag * torch.cos(ph), mag * torch.sin(ph))
+    spec[:, 0].imag.zero_()
+    spec[:, -1].imag.zero_()  # irfft ignores the imaginary part of DC / Nyquist
+    ref = torch.istft(spec, 1024, hop_length=256, win_length=1024, window=torch.hann_window(1024), center=True)
+    out = voc.istft_head(head.cuda()).cpu()
+    assert rel_l2(out, ref) < 1e-5
+    # (2) size-independent property at the benchmark length: ISTFT(STFT(x)) == x  (T = 683 frames = generated part of C2)
+    x = torch.randn(1, 682 * 256, generator=g) * 0.1
+    S = torch.stft(x, 1024, hop_length=256, win_length=1024, window=torch.hann_window(1024), center=True, return_complex=True)
+    head = torch.cat([torch.log(S.abs().clamp_min(1e-7)), torch.angle(S)], dim=1).transpose(1, 2).contiguous()
+    y = voc.istft_head(head.cuda()).cpu()
+    assert y.shape == x.shape and (y - x).abs().max() < 2e-4
+
+
+def _write_tiny_assets(tmp, arch, V, W, vocos_hp, VW):
+    cfg = {"model": {"name": "tiny_custom", "backbone": "DiT", "arch": arch,
+                     "mel_spec": {"target_sample_rate": 24000, "n_mel_channels": 100, "hop_length": 256, "win_length": 1024, "n_fft": 1024,
+                                  "mel_spec_type": "vocos"}}}
+    cfg_path = os.path.join(tmp, "tiny_custom.yaml")
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump(cfg, f)
+    ema = {"ema_model.transformer." + k: v for k, v in W.items()}
+    ema.update({"initted": torch.tensor(True), "step": torch.tensor(7), "ema_model.mel_spec.mel_stft.spectrogram.window": torch.hann_window(1024)})
+    ckpt = os.path.join(tmp, "model_7.pt")
+    torch.save({"ema_model_state_dict": ema}, ckpt)
+    vdir = os.path.join(tmp, "vocos")
+    os.makedirs(vdir)
+    with open(os.path.join(vdir, "config.yaml"), "w") as f:
+        yaml.safe_dump({"feature_extractor": {"init_args": {"n_fft": 1024, "hop_length": 256, "n_mels": 100}},
+                        "backbone": {"init_args": {"input_channels": 100, "dim": vocos_hp["dim"], "intermediate_dim": vocos_hp["intermediate_dim"],
+                                                   "num_layers": vocos_hp["num_layers"]}},
+                        "head": {"init_args": {"dim": vocos_hp["dim"], "n_fft": 1024, "hop_length": 256}}}, f)
+    torch.save({**VW, "feature_extractor.mel_spec.spectrogram.window": torch.hann_window(1024)}, os.path.join(vdir, "pytorch_model.bin"))
+    vocab = os.path.join(tmp, "vocab.txt")
+    with open(vocab, "w", encoding="utf-8") as f:
+        f.write(" \n" + "\n".join(list("abcdefghijklmnopqrstuvwxyz.,!?'")) + "\n")
+    return cfg_path, ckpt, vdir, vocab
+
+
+def test_wrapper_end_to_end(tmp_path):
+    """checkpoint (.pt with ema_model.* keys) + local Vocos dir + vocab file -> preprocess_reference -> generate, and the same
+    mel through the oracle vocoder."""
+    from eraxvif5tts_amd.infer import audio
+    from eraxvif5tts_amd.infer.f5tts_wrapper import F5TTSWrapper
+    arch = dict(dim=128, depth=2, heads=2, ff_mult=2, text_dim=64, conv_layers=2, pe_attn_head=1, text_mask_padding=False)
+    V = 32
+    W = cpu_ref.random_dit_weights(arch, V, seed=5)
+    hp = dict(dim=64, intermediate_dim=128, num_layers=2)
+    VW = cpu_ref.random_vocos_weights(seed=6, dim=64, inter=128, layers=2)
+    cfg_path, ckpt, vdir, vocab = _write_tiny_assets(str(tmp_path), arch, V, W, hp, VW)
+    # 2.2 s synthetic prompt: silence + quiet tone + silence (exercises edge trimming and the rms boost)
+    sr = 24000
+    t = np.arange(int(1.8 * sr)) / sr
+    tone = 0.02 * np.sin(2 * np.pi * 180 * t) * (1 + 0.5 * np.sin(2 * np.pi * 3 * t))
+    wav = np.concatenate([np.zeros(int(0.2 * sr)), tone, np.zeros(int(0.2 * sr))])
+    ref_wav = os.path.join(str(tmp_path), "ref.wav")
+    audio.write_wav(ref_wav, wav, sr)
+
+    tts = F5TTSWrapper(model_name=cfg_path, ckpt_path=ckpt, vocab_file=vocab, use_local_vocoder=True, vocoder_path=vdir, precision="fp32")
+    with pytest.raises(ValueError):
+        tts.generate("hello")
+    aud, ref_text = tts.preprocess_reference(ref_wav, "a quiet tone")
+    assert ref_text == "a quiet tone. "
+    assert aud.shape[0] == 1 and abs(float(torch.sqrt(torch.mean(aud ** 2))) - 0.1) < 2e-3  # boosted to the target rms
+    assert tts.ref_audio_len == aud.shape[-1] // 256 and abs(tts.get_current_audio_length() - 1.85) < 0.05
+    text = "hello there, this is a test. " * 3 + "and one more sentence to force a second chunk, because the budget is small."
+    wave, rate, spec = tts.generate(text, nfe_step=4, return_numpy=True, return_spectrogram=True)
+    assert rate == 24000 and wave.ndim == 1 and np.isfinite(wave).all() and spec.shape[0] == 100
+    # chunking + cross-fade bookkeeping: every chunk contributes (frames - 1) * 256 samples, overlaps of 3600 removed
+    from eraxvif5tts_amd.infer.utils_infer import chunk_text
+    n_chunks = len(chunk_text(text, max_chars=int(len(ref_text.encode()) / tts.get_current_audio_length() * (22 - tts.get_current_audio_length()))))
+    assert n_chunks >= 2
+    assert len(wave) == (spec.shape[1] - n_chunks) * 256 - (n_chunks - 1) * 3600
+    # the vocoder half against the oracle on the very same mel
+    ref_wave = cpu_ref.vocos_decode({k: v for k, v in VW.items()}, torch.from_numpy(spec[None, :, : 40]).float())
+    got = tts.vocoder.decode(torch.from_numpy(spec[None, :, : 40]).float().cuda()).cpu()
+    assert rel_l2(got, ref_wave) < 1e-4
+    out_path = os.path.join(str(tmp_path), "out", "gen.wav")
+    assert tts.generate("short one.", output_path=out_path, nfe_step=2) == out_path and os.path.getsize(out_path) > 44

@@ -1,0 +1,160 @@
+"""CPU tests of the host side: tokenizer / text front-end against vectors captured from the reference, chunk_text and the
+duration / cross-fade rules against hand-derived cases, the C-ABI surface of libf5hip.so, and CFM's host logic (driven over
+a torch backbone built from the CPU oracle) against the reference golden vectors."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden_arch, golden_weights, load_golden, rel_l2
+
+
+def test_tokenizer_and_ids_match_reference():
+    from eraxvif5tts_amd.infer.utils_infer import DEFAULT_VOCAB
+    from eraxvif5tts_amd.model.utils import get_tokenizer, lens_to_mask, list_str_to_idx
+    z = load_golden("host_logic")
+    vmap, vsize = get_tokenizer(DEFAULT_VOCAB, "custom")
+    assert vsize == int(z["vocab_size"]) == 2545 and vmap[" "] == 0
+    for tok, idx in zip(z["probe_tokens"], z["probe_ids"]):
+        assert vmap.get(str(tok), -1) == int(idx)
+    ids = list_str_to_idx([list(str(t)) for t in z["texts"]], vmap)
+    assert np.array_equal(ids.numpy(), z["ids"])  # OOV -> 0, batch padding -1
+    lens = torch.from_numpy(z["lens"])
+    assert np.array_equal(lens_to_mask(lens).numpy(), z["mask"])
+    assert np.array_equal(lens_to_mask(lens, length=9).numpy(), z["mask_len9"])
+    with pytest.raises(FileNotFoundError):
+        get_tokenizer("/nonexistent/vocab.txt", "custom")
+
+
+def test_convert_char_to_pinyin_non_han_rules():
+    from eraxvif5tts_amd.model.utils import convert_char_to_pinyin
+    out = convert_char_to_pinyin(["hello world; “quoted” it’s"])[0]
+    assert "".join(out) == 'hello world, "quoted" it\'s'  # ; -> , and curly -> straight quotes (utils.py:249-251)
+    # a multi-letter ASCII run directly after a non-ASCII letter gets a space in front (utils.py:263-266)
+    assert "".join(convert_char_to_pinyin(["trường"])[0]) == "trườ ng"
+    assert convert_char_to_pinyin(["a b"])[0] == ["a", " ", "b"]
+
+
+def test_chunk_text_byte_budget():
+    from eraxvif5tts_amd.infer.utils_infer import chunk_text
+    text = "Xin chào các bạn. Hôm nay trời đẹp, chúng ta đi chơi nhé! Được không? Tất nhiên rồi."
+    chunks = chunk_text(text, max_chars=40)
+    assert chunks == ["Xin chào các bạn.", "Hôm nay trời đẹp,", "chúng ta đi chơi nhé!", "Được không? Tất nhiên rồi."]
+    assert all(len(c.encode("utf-8")) <= 40 + 1 for c in chunks)
+    assert chunk_text("one. two. three.", max_chars=1000) == ["one. two. three."]
+    assert chunk_text("", max_chars=10) == []
+    assert chunk_text("你好。世界。", max_chars=6) == ["你好。", "世界。"]  # CJK punctuation splits without whitespace
+
+
+def test_cross_fade_rule():
+    from eraxvif5tts_amd.infer.utils_infer import cross_fade_concat
+    a, b = np.ones(10000, np.float32), np.zeros(8000, np.float32)
+    out = cross_fade_concat([a, b], 0.15)
+    n = 3600  # 0.15 s * 24000
+    assert len(out) == 10000 + 8000 - n
+    assert np.allclose(out[10000 - n: 10000], np.linspace(1, 0, n))
+    assert len(cross_fade_concat([a, b], 0.0)) == 18000
+    short = np.ones(100, np.float32)
+    assert len(cross_fade_concat([short, b], 0.15)) == 8000  # fade limited to the shorter chunk
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from eraxvif5tts_amd import _lib
+    header = open(os.path.join(ROOT, "include", "f5hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(f5_[a-z0-9_]+)\s*\(", header)))
+    lib = _lib.load(build_if_missing=True)
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(_lib.EXPORTS) == declared
+    assert lib.f5_version() == 100
+
+
+def test_product_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from eraxvif5tts_amd import _lib
+    from eraxvif5tts_amd.model import CFM, DiT
+    m = DiT(dim=128, depth=1, heads=2, ff_mult=2, text_dim=64, conv_layers=1, text_num_embeds=10, mel_dim=100)
+    c = CFM(transformer=m, mel_spec_kwargs={"mel_spec_type": "vocos"})
+    with pytest.raises(_lib.F5HipError):
+        c.sample(cond=torch.randn(1, 10, 100), text=torch.randint(0, 10, (1, 5)), duration=20, steps=2)
+    with pytest.raises(_lib.F5HipError):
+        m(x=torch.randn(1, 8, 100), cond=torch.randn(1, 8, 100), text=torch.zeros(1, 4, dtype=torch.long), time=torch.tensor(0.5),
+          drop_audio_cond=False, drop_text=False)
+
+
+class _OracleBackbone(torch.nn.Module):
+    """plug point A accepts any module: a CPU torch backbone evaluated by the oracle lets CFM's host logic (duration rule,
+    masks, noise, sway grid, CFG, solver loop, final where) run on CPU against the reference golden vectors."""
+
+    def __init__(self, W, cfg):
+        super().__init__()
+        from oracle import cpu_ref
+        self.W, self.cfg, self.ref, self.dim = W, cfg, cpu_ref, cfg["dim"]
+        self.p = torch.nn.Parameter(torch.zeros(1))
+        self.cleared = 0
+
+    def forward(self, x, cond, text, time, drop_audio_cond, drop_text, mask=None, cache=False):
+        return self.ref.dit_forward(self.W, self.cfg, x, cond, text, time, drop_audio_cond, drop_text, mask=mask)
+
+    def clear_cache(self):
+        self.cleared += 1
+
+
+@pytest.mark.parametrize("name", ["tiny_base", "tiny_v1"])
+def test_cfm_host_logic_against_reference_golden(name):
+    from eraxvif5tts_amd.model import CFM
+    z = load_golden(name)
+    bb = _OracleBackbone(golden_weights(z), golden_arch(z))
+    c = CFM(transformer=bb, mel_spec_kwargs={"mel_spec_type": "vocos"})
+    out, traj = c.sample(cond=torch.from_numpy(z["cond"]), text=torch.from_numpy(z["text"]), duration=torch.from_numpy(z["duration"]),
+                         lens=torch.from_numpy(z["lens"]), steps=int(z["steps"]), cfg_strength=float(z["cfg_strength"]),
+                         sway_sampling_coef=float(z["sway"]), seed=int(z["seed"]))
+    assert torch.equal(traj[0], torch.from_numpy(z["y0"]))  # per-sample manual_seed + randn, zero padded (cfm.py:178-183)
+    assert rel_l2(out, z["out"]) < 2e-5 and rel_l2(traj, z["traj"]) < 2e-5
+    assert bb.cleared == 1
+
+
+def test_cfm_midpoint_and_duration_rule():
+    from eraxvif5tts_amd.model import CFM
+    z = load_golden("tiny_b1_midpoint")
+    bb = _OracleBackbone(golden_weights(z), golden_arch(z))
+    c = CFM(transformer=bb, mel_spec_kwargs={"mel_spec_type": "vocos"}, odeint_kwargs={"method": "midpoint"})
+    out, traj = c.sample(cond=torch.from_numpy(z["cond"]), text=torch.from_numpy(z["text"]), duration=int(z["duration"]), steps=int(z["steps"]),
+                         cfg_strength=0.0, sway_sampling_coef=float(z["sway"]), seed=int(z["seed"]))
+    assert out.shape[1] == 41 and rel_l2(out, z["out_cfg0"]) < 2e-5
+
+
+def test_mel_front_end_matches_oracle():
+    from eraxvif5tts_amd.model.modules import MelSpec
+    from oracle import cpu_ref
+    wav = torch.randn(2, 6000, generator=torch.Generator().manual_seed(0)) * 0.1
+    assert torch.allclose(MelSpec()(wav), cpu_ref.mel_spectrogram(wav), atol=1e-5)
+
+
+def test_audio_front_end():
+    from eraxvif5tts_amd.infer import audio
+    sr = 24000
+    t = np.arange(int(2.0 * sr)) / sr
+    tone = (0.3 * np.sin(2 * np.pi * 220 * t) * 32767).astype(np.int32)
+    x = np.concatenate([np.zeros(int(0.3 * sr), np.int32), tone, np.zeros(int(0.4 * sr), np.int32)])
+    seg = audio.Segment(x, sr, 2)
+    assert len(seg) == 2700 and abs(seg.slice_ms(300, 2300).dBFS - 20 * np.log10(0.3 / np.sqrt(2))) < 0.05
+    trimmed = audio.remove_silence_edges(seg)
+    assert abs(len(trimmed) - 2000) <= 10
+    assert audio.detect_leading_silence(seg, -42) == 300
+    assert audio.detect_nonsilent(seg, min_silence_len=100, silence_thresh=-40, seek_step=10)[0][0] in range(290, 311)
+    # resampler: a 440 Hz tone keeps its frequency and amplitude through 16 kHz -> 24 kHz
+    t16 = torch.arange(16000) / 16000.0
+    y = audio.resample(torch.sin(2 * np.pi * 440 * t16)[None], 16000, 24000)
+    assert y.shape == (1, 24000)
+    ref = torch.sin(2 * np.pi * 440 * torch.arange(24000) / 24000.0)
+    assert (y[0, 200:-200] - ref[200:-200]).abs().max() < 5e-3
+    # wav round trip
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".wav") as f:
+        audio.write_wav(f.name, trimmed.samples[:, 0] / 32768.0, sr)
+        back, sr2, width = audio.read_wav(f.name)
+        assert sr2 == sr and width == 2 and np.abs(back[:, 0] - trimmed.samples[:, 0]).max() <= 1
