@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 BASE_ARCH = dict(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, text_mask_padding=False, conv_layers=4, pe_attn_head=1)
 VOCAB = 2545
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+QKV_TRAFFIC_BYTES = int((546661.1875 * 2 + 401031.1875) * 1024)  # profiles/r1_04_c2_l2_patch_order_kernel_stats.md
 
 
 def synth_weights(model, seed=0):
@@ -70,16 +71,16 @@ def cpu_baseline(model, N, seconds_hint=20):
     W = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     g = torch.Generator().manual_seed(1)
     n_ref = N // 3
-    cond = (torch.randn(1, n_ref, 100, generator=g) * 2 - 3).clamp(math.log(1e-5), 3.0)
-    text = torch.randint(0, VOCAB, (1, N // 6), generator=g)
-    nfe = 1
+    bs, nfe = 2, 2
+    cond = (torch.randn(bs, n_ref, 100, generator=g) * 2 - 3).clamp(math.log(1e-5), 3.0)
+    text = torch.randint(0, VOCAB, (bs, N // 6), generator=g)
     t0 = time.perf_counter()
     cpu_ref.sample(W, BASE_ARCH, cond, text, N, steps=nfe, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0, return_trajectory=False)
     dt = time.perf_counter() - t0
-    value = N / (dt * 32 / nfe)
+    value = bs * N / (dt * 32 / nfe)
     return {"value": round(value, 3), "unit": "mel-frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/cpu_ref.sample fp32 torch, B=1 N={N} NFE={nfe} CFG=2 ({2 * nfe} network evaluations, {dt:.1f} s), "
-                      f"scaled linearly to NFE=32"}
+            "sample": f"oracle/cpu_ref.sample fp32 torch, B={bs} N={N} NFE={nfe} CFG=2 ({2 * nfe} network evaluations of {bs} utterances, "
+                      f"{dt:.1f} s), scaled linearly to NFE=32"}
 
 
 def main():
@@ -172,7 +173,10 @@ def main():
             _lib.check(lib.f5_bench_gemm_site(0, 0, rows, N, 1024, 16, 2048, 3, C.byref(ms), _lib.stream_ptr()), "bench_gemm_site")
         achieved = flops / (ms.value * 1e-3) / 1e12
         result["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                              "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
+                              # HBM-side bytes per launch from the rocprofv3 PMC passes recorded in profiles/r1_04_* (FETCH_SIZE x 2 on gfx950
+                              # + WRITE_SIZE); only meaningful for the default C2 shape, null otherwise
+                              "traffic": QKV_TRAFFIC_BYTES if (rows == 65536 and N == 1024) else None,
                               "kernel": ("gemm_fast" if kernel_kind == 1 else "gemm_tile") + "<bf16, QKV+RoPE epilogue>",
                               "launch": f"M={rows} N=3072 K=1024, {flops / 1e9:.1f} GFLOP, {ms.value:.4f} ms/launch (HIP events, 10 launches)"}
         # whole-loop MFMA fraction from the algorithmic FLOPs of SURVEY.md 8(d)

@@ -29,7 +29,18 @@ __global__ __launch_bounds__(256, 2) void attn_fast_kernel(const bf16_t* __restr
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [buf][K | V]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
+    // XCD-aware block -> (batch*head, query block) map: blocks id and id+8 share an XCD (and its L2), so all query blocks of one
+    // (batch, head) are given ids with equal id % 8: its K/V (256 KiB at N = 1024) are then fetched from HBM once per XCD pass
+    // instead of once per query block.  Falls back to the plain order when B*H is not a multiple of 8.
+    const int QB = gridDim.x, BH = gridDim.y * gridDim.z;
+    int qb = blockIdx.x, bh = blockIdx.y + blockIdx.z * gridDim.y;
+    if ((BH & 7) == 0) {
+        const int id = blockIdx.x + QB * bh;  // linear dispatch order (x fastest)
+        const int xcd = id & 7, j = id >> 3;
+        qb = j % QB;
+        bh = (j / QB) * 8 + xcd;
+    }
+    const int b = bh / gridDim.y, head = bh - b * gridDim.y, q0 = qb * 128 + wave * 32;
     const int r = lane & 31, h = lane >> 5;
     const bf16_t* base = qkv + (size_t)b * N * ldq + head * 64;
     const bf16_t* kbase = base + inner;

@@ -45,6 +45,7 @@ struct GemmParams {
     int rope_heads;          // heads that receive RoPE
     // CONV31: channels per group (dim/16) and the padded input-channel window one 64-channel output tile reads
     int conv_cg, conv_win;
+    int tile_group;  // tuned kernel: token tiles per L2 patch (set by the launcher)
 };
 
 // kernel_kind: 0 = reference tile kernel (any shape), 1 = tuned 256x256 LDS-DMA bf16 kernel

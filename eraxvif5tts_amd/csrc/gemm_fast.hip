@@ -50,9 +50,9 @@ __device__ __forceinline__ void dma16(const void* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
-template <int BN, int WM, int MODE, int EPI, int VAR>
+template <int BN, int WM, int MODE, int EPI, int VAR, int NS>
 __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(GemmParams p, int tiles_n, int nblocks) {
-    constexpr int BM = 256, BK = 32, WN = 64, NSTAGE = 4;
+    constexpr int BM = 256, BK = 32, WN = 64, NSTAGE = NS;
     constexpr int WAVES_N = BN / WN;
     constexpr int MI = WM / 16, NI = WN / 16;
     constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
@@ -68,7 +68,15 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
     const int bid = blockIdx.x;
     const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int tile_m = swz / tiles_n, tile_n = swz - tile_m * tiles_n;
+    // inside an XCD band, walk groups of `gm` token tiles x all feature tiles with the token tile fastest: the ~32 tiles an
+    // XCD runs together then form a squarer (gm x 32/gm) patch of the output, which minimises the distinct operand slices
+    // its L2 has to hold per K-step
+    const int gm = p.tile_group > 0 ? p.tile_group : 1;
+    const int tiles_m_all = nblocks / tiles_n;
+    const int grp = swz / (gm * tiles_n);
+    const int gsz = min(gm, tiles_m_all - grp * gm);  // last group may be short
+    const int rin = swz - grp * gm * tiles_n;
+    const int tile_n = rin / gsz, tile_m = grp * gm + (rin - tile_n * gsz);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
@@ -112,8 +120,13 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
 
     // piece ids of one K-step for this wave: 0,1 = activation pieces, 2.. = weight pieces
     auto issue_piece = [&](int kt, int piece) {
-        char* sbase = smem + (kt & (NSTAGE - 1)) * STAGE;
-        if constexpr (MODE == GEMM_DENSE) {
+        char* sbase = smem + (kt % NSTAGE) * STAGE;
+        if constexpr (VAR == 13) {
+            // timing-only: same bytes per piece, but 8 rows x 128 B (whole cache lines) instead of 16 rows x 64 B
+            const bf16_t* base = piece < 2 ? A + (size_t)(m0 + (wave * 2 + piece) * 8 + (lane >> 3)) * p.lda
+                                           : W + (size_t)(n0 + (wave * 2 + piece - 2) * 8 + (lane >> 3)) * p.ldw;
+            dma16(base + (size_t)kt * BK + (lane & 7) * 8, sbase + (piece < 2 ? (wave * 2 + piece) * 1024 : A_BYTES + w_piece[piece - 2] * 1024));
+        } else if constexpr (MODE == GEMM_DENSE) {
             if (piece < 2)
                 dma16(a_src[piece] + (size_t)kt * BK, sbase + (wave * 2 + piece) * 1024);
             else
@@ -171,7 +184,7 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
         for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto read_frags = [&](int kt, bf16x8 (&wf)[NI], bf16x8 (&af)[MI]) {
-        const char* sb = smem + (kt & (NSTAGE - 1)) * STAGE;
+        const char* sb = smem + (kt % NSTAGE) * STAGE;
 #pragma unroll
         for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + w_off + i * 1024);
 #pragma unroll
@@ -184,102 +197,89 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
             for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
     };
 
-    issue(0);
-    if (nk > 1) issue(1);
-    if (nk > 2) issue(2);
-    if constexpr (VAR == 0) {
-        // ---- ring, fragments read and consumed in the same K-step: slot t&3 is consumed while K-steps t+1..t+3 are in flight
-        for (int kt = 0; kt < nk; ++kt) {
-            // my own pieces of K-step kt have landed once at most the pieces of the younger K-steps are still outstanding
-            if (kt + 2 < nk)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-            else if (kt + 1 < nk)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // every wave's pieces of K-step kt have landed AND every wave has finished reading slot (kt-1)&3
-            __builtin_amdgcn_s_barrier();
-            if (kt + 3 < nk) issue(kt + 3);  // refills slot (kt-1)&3
-            bf16x8 wf[NI], af[MI];
-            read_frags(kt, wf, af);
-            mma(wf, af);
-        }
-    } else if constexpr (VAR == 1) {
-        // ---- ring + staggered wave groups (the two waves that share a SIMD never run the same phase together):
-        //   every wave alternates  P_k: {refill slot (k-1)&3 by DMA, ds_read the fragments of K-step k, counted vmcnt for
-        //   K-step k+1}  |barrier|  C_k: {32 MFMAs}  |barrier| ...; waves 4-7 run one barrier interval behind waves 0-3,
-        //   so in every interval one group feeds the matrix pipe while its SIMD partners do their LDS/DMA work.
-        const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
-        if (nk > 2)
+    // wait until at most `tiles` K-steps' worth of this wave's DMA pieces are still outstanding (vmcnt retires in order)
+    auto wait_pieces = [&](int tiles) {
+        if (tiles >= 3)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory");
+        else if (tiles == 2)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-        else if (nk > 1)
+        else if (tiles == 1)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // K-step 0 has landed for every wave
+    };
+    constexpr int D = NSTAGE - 1;  // K-steps in flight ahead of the one being consumed
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < nk) issue(d);
+    wait_pieces(min(D - 1, nk - 1));  // K-step 0 has landed for this wave
+    __builtin_amdgcn_s_barrier();     // ... and for every wave
+
+    if constexpr (VAR == 0) {
+        // ---- plain ring: every wave does {refill, fragment reads, MFMAs} per K-step, one barrier per K-step
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + D < nk) issue(kt + D);  // refills slot (kt-1) % NSTAGE: its readers passed the previous barrier
+            bf16x8 wf[NI], af[MI];
+            read_frags(kt, wf, af);
+            mma(wf, af);
+            if (kt + 1 < nk) {
+                wait_pieces(min(kt + D, nk - 1) - (kt + 1));
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+    } else {
+        // ---- ring + staggered wave groups (the two waves that share a SIMD never run the same phase together):
+        //   every wave alternates  P_k: {refill slot (k-1) % NSTAGE by DMA, ds_read the fragments of K-step k, counted vmcnt
+        //   for K-step k+1}  |barrier|  C_k: {32 MFMAs}  |barrier| ...; waves 4-7 run one barrier interval behind waves 0-3,
+        //   so in every interval one group feeds the matrix pipe while its SIMD partners do their LDS/DMA work.
+        // VAR >= 10: timing-only ablations (results are wrong by construction): 10 no DMA in the loop, 11 fragments read once, 12 no MFMA
+        const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
         if (late) __builtin_amdgcn_s_barrier();
         bf16x8 wf[NI], af[MI];
         for (int kt = 0; kt < nk; ++kt) {
-            // -- P_kt.  Slot (kt-1)&3 is free: both groups retired their reads of it (lgkmcnt(0) below) at least one barrier ago.
-            if (kt + 3 < nk) issue(kt + 3);
-            read_frags(kt, wf, af);
+            // -- P_kt.  Slot (kt-1) % NSTAGE is free: both groups retired their reads of it (lgkmcnt(0) below) at least one barrier ago.
+            if constexpr (VAR == 3) {
+                if (kt + D < nk) {
+#pragma unroll
+                    for (int pc = 0; pc < PPW / 2; ++pc) issue_piece(kt + D, pc);
+                }
+            } else {
+                if (VAR != 10 && kt + D < nk) issue(kt + D);
+            }
+            if (VAR != 11 || kt == 0) read_frags(kt, wf, af);
             // my pieces of K-step kt+1 must have landed before the barrier that precedes anybody's P_{kt+1}
-            if (kt + 3 < nk)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-            else if (kt + 2 < nk)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait_pieces(kt + 1 < nk ? min(kt + D, nk - 1) - (kt + 1) : 0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             // -- C_kt
             __builtin_amdgcn_s_setprio(1);
-            mma(wf, af);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-        }
-        if (!late) __builtin_amdgcn_s_barrier();  // same barrier count for both groups
-    } else {
-        // ---- staggered wave groups, DMA issue moved from the load phase into the MFMA phase: the LDS-DMA pieces of
-        //      K-step kt+3 are issued between groups of MFMAs (they do not use the matrix pipe), which shortens the load
-        //      phase P_k to {12 ds_reads + waits} so both barrier intervals are about one MFMA cluster long.
-        const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
-        if (nk > 2)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-        else if (nk > 1)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (late) __builtin_amdgcn_s_barrier();
-        bf16x8 wf[NI], af[MI];
-        for (int kt = 0; kt < nk; ++kt) {
-            // -- P_kt: fragments of K-step kt; my pieces of K-step kt+1 landed (kt+2 may be outstanding, kt+3 is issued in C_kt)
-            read_frags(kt, wf, af);
-            if (kt + 2 < nk)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            // -- C_kt: 32 MFMAs with the DMA pieces of K-step kt+3 (slot (kt-1)&3, retired two barriers ago) in between
-            __builtin_amdgcn_s_setprio(1);
-            const bool more = kt + 3 < nk;
+            if constexpr (VAR == 3) {
+                // second half of the DMA pieces rides in the MFMA phase (balances the two barrier intervals)
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
+                for (int i = 0; i < NI; ++i) {
 #pragma unroll
-                for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
-                if (i < PPW && more) issue_piece(kt + 3, i);
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+                    if (i == NI / 2 - 1 && kt + D < nk) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int pc = PPW / 2; pc < PPW; ++pc) issue_piece(kt + D, pc);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else if constexpr (VAR != 12 && VAR != 13) {
+                mma(wf, af);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(wf[i]));
+#pragma unroll
+                for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(af[j]));
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
         }
-        if (!late) __builtin_amdgcn_s_barrier();
+        if (!late) __builtin_amdgcn_s_barrier();  // same barrier count for both groups
     }
 
     // ---------------------------------------------------------------- epilogue (store-only wherever the call site allows)
@@ -378,17 +378,33 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
     });
 }
 
-int g_gemm_variant = 1;  // tuning knob (f5_tuning_set("gemm_variant", v)): 0 = ring, 1 = ring + staggered wave groups, 2 = staggered + DMA issue inside the MFMA phase
+int g_gemm_variant = 1;  // tuning knob (f5_tuning_set("gemm_variant", v)): 0 = plain ring, 1 = ring + staggered wave groups, 10-12 ablations
+int g_gemm_group = 8;    // tuning knob ("gemm_group"): token tiles per L2 patch (1 = feature-tile-fastest order)
+int g_gemm_stages = 4;   // tuning knob ("gemm_stages"): LDS ring slots of the 256x256 tile (4 = 128 KiB, 5 = 160 KiB = the whole LDS)
 
-template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmParams& p, hipStream_t stream) {
+template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmParams& p0, hipStream_t stream) {
+    GemmParams p = p0;
+    p.tile_group = g_gemm_group;
     const int tiles_m = cdiv(p.M, 256), tiles_n = cdiv(p.N, BN);
     const int nblocks = tiles_m * tiles_n;
-    if (BN == 256 && g_gemm_variant == 1)
-        hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, (BN == 256 ? 1 : 0)>), dim3(nblocks), dim3(512), 0, stream, p, tiles_n, nblocks);
-    else if (BN == 256 && g_gemm_variant == 2)
-        hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, (BN == 256 ? 2 : 0)>), dim3(nblocks), dim3(512), 0, stream, p, tiles_n, nblocks);
-    else
-        hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 0>), dim3(nblocks), dim3(512), 0, stream, p, tiles_n, nblocks);
+    dim3 grid(nblocks), block(512);
+    if constexpr (BN == 256) {
+        if (g_gemm_variant == 0)
+            hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 0, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
+        else if (g_gemm_variant >= 10 && EPI == EPI_GATE_T) {
+            if (g_gemm_variant == 10) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 10, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
+            if (g_gemm_variant == 11) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 11, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
+            if (g_gemm_variant == 12) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 12, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
+            if (g_gemm_variant == 13) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 13, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
+        } else if (g_gemm_variant == 3)
+            hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 3, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
+        else if (g_gemm_stages == 5)
+            hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 1, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
+        else
+            hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 1, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
+    } else {
+        hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 0, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
+    }
     F5_LAUNCH_CHECK();
     return 0;
 }

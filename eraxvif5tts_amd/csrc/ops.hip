@@ -132,6 +132,8 @@ __global__ __launch_bounds__(256) void fill_random_f32_kernel(float* dst, size_t
     dst[i] = ((float)(x >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale;
 }
 
+static int g_bench_pad_a = 0, g_bench_pad_w = 0;
+
 // Times `iters` back-to-back launches of ONE GEMM kernel (bf16, the epilogue/shape of the DiT call site `site`) with HIP
 // events on `stream`; *ms_avg = average device time of one launch.  site: 0 = fused QKV projection + RoPE (N = 3*inner),
 // 1 = FF1 + GELU-tanh, 2 = FF2 + gate, 3 = attention out-projection + gate (store-only residual branches).
@@ -150,27 +152,28 @@ extern "C" int f5_bench_gemm_site(int kernel, int site, int rows, int seq, int d
         default: return f5_fail(F5_EINVAL, "bad site");
     }
     const size_t Mp = (size_t)round_up(rows, 256);
+    const int lda = K + g_bench_pad_a, ldw = K + g_bench_pad_w;  // leading-dimension padding experiments (tuning knobs)
     DevArena a;
     void *A = nullptr, *W = nullptr, *out = nullptr;
     float *bias = nullptr, *resid = nullptr, *gate = nullptr, *rope = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = 0;
     do {
-        if ((rc = a.alloc(&A, Mp * K * 2))) break;
-        if ((rc = a.alloc(&W, (size_t)round_up(N, 256) * K * 2))) break;
+        if ((rc = a.alloc(&A, Mp * lda * 2))) break;
+        if ((rc = a.alloc(&W, (size_t)round_up(N, 256) * ldw * 2))) break;
         if ((rc = a.alloc(&out, Mp * N * 2))) break;
         if ((rc = a.alloc_t(&bias, (size_t)N))) break;
         if ((rc = a.alloc_t(&resid, Mp * (size_t)dim))) break;
         if ((rc = a.alloc_t(&gate, (size_t)dim))) break;
         if ((rc = a.alloc_t(&rope, (size_t)seq * 64))) break;
-        hipLaunchKernelGGL(fill_random_kernel, dim3((unsigned)((Mp * K + 255) / 256)), dim3(256), 0, st, (uint16_t*)A, Mp * K, 1u, 1.0f);
-        hipLaunchKernelGGL(fill_random_kernel, dim3((unsigned)(((size_t)N * K + 255) / 256)), dim3(256), 0, st, (uint16_t*)W, (size_t)N * K, 2u, 0.05f);
+        hipLaunchKernelGGL(fill_random_kernel, dim3((unsigned)((Mp * lda + 255) / 256)), dim3(256), 0, st, (uint16_t*)A, Mp * lda, 1u, 1.0f);
+        hipLaunchKernelGGL(fill_random_kernel, dim3((unsigned)(((size_t)N * ldw + 255) / 256)), dim3(256), 0, st, (uint16_t*)W, (size_t)N * ldw, 2u, 0.05f);
         hipLaunchKernelGGL(fill_random_f32_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, bias, (size_t)N, 3u, 0.1f);
         hipLaunchKernelGGL(fill_random_f32_kernel, dim3((unsigned)((dim + 255) / 256)), dim3(256), 0, st, gate, (size_t)dim, 4u, 0.01f);
         hipLaunchKernelGGL(fill_random_f32_kernel, dim3((unsigned)((seq * 64 + 255) / 256)), dim3(256), 0, st, rope, (size_t)seq * 64, 5u, 0.7f);
         GemmParams g;
         memset(&g, 0, sizeof(g));
-        g.A = A; g.lda = K; g.W = W; g.ldw = K; g.M = rows; g.N = N; g.K = K; g.bias = bias; g.rows_per_batch = seq;
+        g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = rows; g.N = N; g.K = K; g.bias = bias; g.rows_per_batch = seq;
         if (epi == EPI_ROPE_T) { g.out_t = out; g.ldo = N; g.rope = rope; g.rope_inner = inner; g.rope_heads = 1; }
         if (epi == EPI_STORE_T) { g.out_t = out; g.ldo = N; g.act = ACT_GELU_TANH; }
         if (epi == EPI_GATE_T) { g.out_t = out; g.ldo = N; g.gate = gate; g.gate_bstride = 0; }
@@ -225,11 +228,27 @@ extern "C" int f5_bench_attention(int kernel, int B, int N, int H, int iters, fl
     return sync_and_release(a, st, rc);
 }
 
-extern int g_gemm_variant;
+extern int g_gemm_variant, g_gemm_stages, g_gemm_group;
 extern "C" int f5_tuning_set(const char* key, int value) {
     if (!key) return f5_fail(F5_EINVAL, "null key");
     if (strcmp(key, "gemm_variant") == 0) {
         g_gemm_variant = value;
+        return 0;
+    }
+    if (strcmp(key, "gemm_group") == 0) {
+        g_gemm_group = value;
+        return 0;
+    }
+    if (strcmp(key, "gemm_stages") == 0) {
+        g_gemm_stages = value;
+        return 0;
+    }
+    if (strcmp(key, "bench_pad_a") == 0) {
+        g_bench_pad_a = value;
+        return 0;
+    }
+    if (strcmp(key, "bench_pad_w") == 0) {
+        g_bench_pad_w = value;
         return 0;
     }
     return f5_fail(F5_EINVAL, "unknown tuning key '%s'", key);
