@@ -155,10 +155,13 @@ __global__ __launch_bounds__(256, 2) void attn_fast_kernel(const bf16_t* __restr
                 rs += pv;
             }
         l_run = l_run * alpha + rs;
+        // the running max settles after the first tiles: skip the 32-register rescale when no query of this wave moved its max
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            o_acc[0][i] *= alpha;
-            o_acc[1][i] *= alpha;
+            for (int i = 0; i < 16; ++i) {
+                o_acc[0][i] *= alpha;
+                o_acc[1][i] *= alpha;
+            }
         }
         // ---- O^T += V^T . P^T
 #pragma unroll

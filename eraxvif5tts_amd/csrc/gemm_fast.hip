@@ -40,6 +40,18 @@ __device__ __forceinline__ float fast_mish(float x) {
     const float n = w * (w + 2.0f);
     return x > 20.0f ? x : x * n * __builtin_amdgcn_rcpf(n + 2.0f);
 }
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+// Two adjacent 16-feature tiles of one token tile: lane (row r = lane>>4) holds features 4r..4r+3 of tile A and of tile B.
+// v_permlane16_swap exchanges the odd 16-lane rows of A with the even rows of B, after which every lane owns 8 consecutive
+// features (rows 0/2: tile A features 8*(r>>1).., rows 1/3: tile B) -> one 16-byte store instead of two 8-byte ones
+// (the epilogue is store-issue bound).
+__device__ __forceinline__ u32x4 pair_swap(bf16x4 a, bf16x4 b) {
+    const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+    const u32x2 s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+    return u32x4{s0[0], s1[0], s0[1], s1[1]};
+}
 __device__ __forceinline__ bf16x4 to_bf16x4(const f32x4& v) { return bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]}; }
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -176,6 +188,10 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
         const int part = nw / p.rope_inner;
         rope_wave = part < 2 && ((nw - part * p.rope_inner) >> 6) < p.rope_heads;
     }
+
+    // 16-byte paired stores: after pair_swap a lane in 16-lane row r owns features (r&1 ? tile i+1 : tile i) * 16 + 8*(r>>1) .. +7
+    const bool wide_ok = (n0 + wn * WN + WN <= p.N) && (p.ldo & 7) == 0;
+    const int nwide = n0 + wn * WN + 16 * (fq & 1) + 8 * (fq >> 1);
 
     f32x4 acc[NI][MI];
 #pragma unroll
@@ -332,11 +348,11 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
         }
         static_for<JG>([&](auto jc) {
             constexpr int jj = decltype(jc)::value;
+            const size_t mr = (size_t)mrow[jj];
+            f32x4 vals[NI];
             static_for<NI>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 f32x4 v = acc[i][j0 + jj] + bias4[i];
-                const bool ok = okm[jj] && okn[i];
-                const size_t mr = (size_t)mrow[jj];
                 if constexpr (EPI == EPI_STORE_T || EPI == EPI_STORE_F32 || EPI == EPI_GATE_T || EPI == EPI_RESID) {
                     if (p.act == ACT_GELU_TANH) {
 #pragma unroll
@@ -349,31 +365,52 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
                         for (int e = 0; e < 4; ++e) v[e] = act_gelu_erf(v[e]);
                     }
                 }
-                if constexpr (EPI == EPI_STORE_T) {
-                    if (ok) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.out_t) + mr * p.ldo + ncol[i]) = to_bf16x4(v);
-                } else if constexpr (EPI == EPI_STORE_F32) {
-                    if (ok) *reinterpret_cast<f32x4*>(p.out_f + mr * p.ldof + ncol[i]) = v;
-                } else if constexpr (EPI == EPI_GATE_T) {
+                if constexpr (EPI == EPI_GATE_T) {
                     if (p.gate) v *= (p.gate_bstride != 0 ? aux[jj][i] : gate4[i]);
                     if (!keep[jj]) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (ok) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.out_t) + mr * p.ldo + ncol[i]) = to_bf16x4(v);
                 } else if constexpr (EPI == EPI_ROPE_T) {
                     if (rope_wave) {  // x_transformers apply_rotary_pos_emb: adjacent pairs, fp32 math
                         const f32x4 cs = aux[jj][i];
                         v = f32x4{v[0] * cs[0] - v[1] * cs[1], v[1] * cs[0] + v[0] * cs[1], v[2] * cs[2] - v[3] * cs[3], v[3] * cs[2] + v[2] * cs[3]};
                     }
-                    if (ok) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.out_t) + mr * p.ldo + ncol[i]) = to_bf16x4(v);
                 } else if constexpr (EPI == EPI_ADD2) {
                     v += aux[jj][i];
-                    if (ok) {
-                        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.out_t) + mr * p.ldo + ncol[i]) = to_bf16x4(v);
-                        *reinterpret_cast<f32x4*>(p.out_f + mr * p.ldof + ncol[i]) = v;
-                    }
                 } else if constexpr (EPI == EPI_RESID) {
                     if (p.gate) v *= gate4[i];
-                    if (ok && keep[jj]) *reinterpret_cast<f32x4*>(p.out_f + mr * p.ldof + ncol[i]) = aux[jj][i] + v;
+                    v += aux[jj][i];
                 }
+                vals[i] = v;
             });
+            if constexpr (EPI == EPI_STORE_T || EPI == EPI_GATE_T || EPI == EPI_ROPE_T) {
+                bf16_t* orow = reinterpret_cast<bf16_t*>(p.out_t) + mr * p.ldo;
+                if (wide_ok) {  // all four feature tiles of this wave in range and 16-byte alignable: pairwise 16-byte stores
+                    static_for<NI / 2>([&](auto hc) {
+                        constexpr int i = decltype(hc)::value * 2;
+                        const u32x4 q = pair_swap(to_bf16x4(vals[i]), to_bf16x4(vals[i + 1]));
+                        if (okm[jj]) *reinterpret_cast<u32x4*>(orow + nwide + 32 * (i / 2)) = q;
+                    });
+                } else {
+                    static_for<NI>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        if (okm[jj] && okn[i]) *reinterpret_cast<bf16x4*>(orow + ncol[i]) = to_bf16x4(vals[i]);
+                    });
+                }
+            } else {
+                static_for<NI>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    const bool ok = okm[jj] && okn[i];
+                    if constexpr (EPI == EPI_STORE_F32) {
+                        if (ok) *reinterpret_cast<f32x4*>(p.out_f + mr * p.ldof + ncol[i]) = vals[i];
+                    } else if constexpr (EPI == EPI_ADD2) {
+                        if (ok) {
+                            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.out_t) + mr * p.ldo + ncol[i]) = to_bf16x4(vals[i]);
+                            *reinterpret_cast<f32x4*>(p.out_f + mr * p.ldof + ncol[i]) = vals[i];
+                        }
+                    } else if constexpr (EPI == EPI_RESID) {
+                        if (ok && keep[jj]) *reinterpret_cast<f32x4*>(p.out_f + mr * p.ldof + ncol[i]) = vals[i];
+                    }
+                });
+            }
         });
     });
 }
