@@ -231,13 +231,21 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
     wait_pieces(min(D - 1, nk - 1));  // K-step 0 has landed for this wave
     __builtin_amdgcn_s_barrier();     // ... and for every wave
 
-    if constexpr (VAR == 0) {
+    if constexpr (VAR == 0 || VAR == 14) {
+        // (VAR 14: timing-only, this schedule without the MFMAs)
         // ---- plain ring: every wave does {refill, fragment reads, MFMAs} per K-step, one barrier per K-step
         for (int kt = 0; kt < nk; ++kt) {
             if (kt + D < nk) issue(kt + D);  // refills slot (kt-1) % NSTAGE: its readers passed the previous barrier
             bf16x8 wf[NI], af[MI];
             read_frags(kt, wf, af);
-            mma(wf, af);
+            if constexpr (VAR == 0) {
+                mma(wf, af);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(wf[i]));
+#pragma unroll
+                for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(af[j]));
+            }
             if (kt + 1 < nk) {
                 wait_pieces(min(kt + D, nk - 1) - (kt + 1));
                 __builtin_amdgcn_s_barrier();
@@ -433,6 +441,7 @@ template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmPa
             if (g_gemm_variant == 11) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 11, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
             if (g_gemm_variant == 12) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 12, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
             if (g_gemm_variant == 13) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 13, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
+            if (g_gemm_variant == 14) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 14, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
         } else if (g_gemm_variant == 3)
             hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 3, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
         else if (g_gemm_stages == 5)

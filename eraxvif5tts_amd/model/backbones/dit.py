@@ -106,6 +106,7 @@ class DiT(nn.Module):
         self.text_cond, self.text_uncond = None, None  # text cache (reference dit.py:131)
         self._native = None
         self._plans = []
+        self._seen_shapes = {}
         self.register_load_state_dict_post_hook(lambda module, _keys: module._drop_native())
 
     # ------------------------------------------------------------------ native handle management
@@ -215,6 +216,13 @@ class DiT(nn.Module):
         lib = _lib.load()
         B, N = cond.shape[0], cond.shape[1]
         evals = steps * (2 if method == "midpoint" else 1)
+        # capturing + instantiating a ~5000-node graph costs about as much as one small sample(): only replay shapes that recur
+        # (serving with fixed buckets, batch inference); one-off shapes (free-form generate()) run eagerly on the stream
+        key = (B, N, int(text.shape[1]), steps, method, float(cfg_strength), bool(use_mask))
+        seen = self._seen_shapes.get(key, 0)
+        self._seen_shapes[key] = seen + 1
+        if use_graph == "auto":
+            use_graph = seen >= 1
         plan = self.plan(B, N, evals)
         dev = "cuda"
         cond = cond.to(device=dev, dtype=torch.float32).contiguous()

@@ -42,10 +42,10 @@ class CFM(nn.Module):
     @torch.no_grad()
     def sample(self, cond, text, duration, *, lens=None, steps=32, cfg_strength=1.0, sway_sampling_coef=None, seed=None,
                max_duration=4096, vocoder=None, no_ref_audio=False, duplicate_test=False, t_inter=0.1, edit_mask=None,
-               y0=None, return_trajectory=True, use_graph=True):
+               y0=None, return_trajectory=True, use_graph="auto"):
         """Same arguments and return value ``(out, trajectory)`` as the reference.  Extra keyword-only knobs:
         ``y0`` (explicit initial noise, zero-padded [b, N, mel]: parity tests), ``return_trajectory=False`` skips
-        materialising the [steps+1, b, N, mel] trajectory (returned as None), ``use_graph`` toggles hipGraph replay."""
+        materialising the [steps+1, b, N, mel] trajectory (returned as None), ``use_graph`` = True / False / "auto" (default: replay a hipGraph from the second call with the same shape on)."""
         self.eval()
         if cond.ndim == 2:  # raw wave
             cond = self.mel_spec(cond)
