@@ -479,10 +479,17 @@ int launch_gemm_fast(const GemmParams& p, int mode, int epi, hipStream_t stream)
         if (epi == EPI_GATE_T) return launch_fast<64, 32, GEMM_CONV31, EPI_GATE_T>(p, stream);
         return f5_fail(F5_EINVAL, "gemm_fast(conv31): unsupported epilogue %d", epi);
     }
-    const bool wide = p.N % 256 == 0;
-#define F5_FAST_CASE(E)                                                         \
-    case E:                                                                     \
-        return wide ? launch_fast<256, 128, GEMM_DENSE, E>(p, stream) : launch_fast<128, 64, GEMM_DENSE, E>(p, stream);
+    // tile width by occupancy: the 256-wide tile is the efficient one, narrower tiles keep the 256 CUs busy when the token count
+    // is small (single-utterance serving: M = 2 x frames)
+    const int tiles_m = cdiv(p.M, 256);
+    int bn = 256;
+    if (p.N % 256 != 0 || tiles_m * (p.N / 256) < 160) bn = 128;
+    if (bn == 128 && p.N % 64 == 0 && tiles_m * cdiv(p.N, 128) < 160) bn = 64;
+#define F5_FAST_CASE(E)                                                                   \
+    case E:                                                                               \
+        if (bn == 256) return launch_fast<256, 128, GEMM_DENSE, E>(p, stream);            \
+        if (bn == 128) return launch_fast<128, 64, GEMM_DENSE, E>(p, stream);             \
+        return launch_fast<64, 32, GEMM_DENSE, E>(p, stream);
     switch (epi) {
         F5_FAST_CASE(EPI_STORE_T)
         F5_FAST_CASE(EPI_STORE_F32)

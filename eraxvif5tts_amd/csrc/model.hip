@@ -433,9 +433,9 @@ static GemmParams gp_zero() {
 }
 static int run_gemm(f5_plan_s* p, const GemmParams& g, int mode, int epi, hipStream_t st) {
     const int prec = p->m->cfg.precision;
-    // 1 = tuned kernel wherever it can run; -1 (auto) = tuned kernel once the problem fills the chip with 256-row tiles
+    // 1 = tuned kernel wherever it can run; -1 (auto) = tuned kernel from 512 token rows on (narrower tiles keep the CUs busy at small M)
     int kind = 0;
-    if (p->gemm_kernel != 0 && gemm_fast_supported(g, prec, mode, epi) && (p->gemm_kernel == 1 || g.M >= 2048)) kind = 1;
+    if (p->gemm_kernel != 0 && gemm_fast_supported(g, prec, mode, epi) && (p->gemm_kernel == 1 || g.M >= 512)) kind = 1;
     return launch_gemm(g, prec, mode, epi, kind, st);
 }
 static float* tap_dst(f5_plan_s* p, const std::string& name) {
