@@ -103,8 +103,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        ndev = torch.cuda.device_count()
+        torch.cuda.set_device(local_rank % max(ndev, 1))
+        backend = os.environ.get("F5_BENCH_BACKEND", "nccl")  # nccl == RCCL on ROCm; gloo only to rehearse the N>1 path on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        else:
+            dist.init_process_group(backend)
     else:
         dist = None
         torch.cuda.set_device(0)

@@ -130,14 +130,44 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
     const int win0 = MODE == GEMM_CONV31 ? (n0 / p.conv_cg) * p.conv_cg : 0;
     const int L = p.rows_per_batch;
 
+    // ---- VAR 20 ("half-slab ring"): the ring unit is {128 token rows + 128 weight rows} x 64 k, so every DMA piece is 8 rows of
+    //      one whole, aligned 128-byte line (measured: +45 % LDS-DMA rate vs 16 rows x 64 B).  K-step t (64 deep) = half-slabs
+    //      2t (rows 0-127 of both operands) and 2t+1 (rows 128-255); it is consumed as two 32-deep sub-steps.
+    [[maybe_unused]] const bf16_t* hs_a[2][2];  // [half r][piece j]
+    [[maybe_unused]] const bf16_t* hs_w[2][2];
+    if constexpr (VAR == 20) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = (wave * 2 + j) * 8 + (lane >> 3);          // row inside the half-slab operand (0..127)
+            const int lc = (lane & 7) ^ ((row >> 1) & 7);              // logical 16-byte chunk kept at this physical slot
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                int gmr = m0 + 128 * r + row;
+                if (gmr >= p.M) gmr = p.M - 1;
+                if (p.a_row_mod > 0) gmr %= p.a_row_mod;
+                hs_a[r][j] = A + (size_t)gmr * p.lda + lc * 8;
+                int gnr = n0 + 128 * r + row;
+                if (gnr >= p.N) gnr = p.N - 1;
+                hs_w[r][j] = W + (size_t)gnr * p.ldw + lc * 8;
+            }
+        }
+    }
+
     // piece ids of one K-step for this wave: 0,1 = activation pieces, 2.. = weight pieces
     auto issue_piece = [&](int kt, int piece) {
         char* sbase = smem + (kt % NSTAGE) * STAGE;
-        if constexpr (VAR == 13) {
-            // timing-only: same bytes per piece, but 8 rows x 128 B (whole cache lines) instead of 16 rows x 64 B
+        if constexpr (VAR == 20) {
+            // kt = half-slab index h: K range [64 * (h >> 1), +64), operand rows 128 * (h & 1) ..
+            const int t = kt >> 1, r = kt & 1;
+            if (piece < 2)
+                dma16((r ? hs_a[1][piece] : hs_a[0][piece]) + (size_t)t * 64, sbase + (wave * 2 + piece) * 1024);
+            else
+                dma16((r ? hs_w[1][piece - 2] : hs_w[0][piece - 2]) + (size_t)t * 64, sbase + A_BYTES + (wave * 2 + piece - 2) * 1024);
+        } else if constexpr (VAR == 13) {
+            // timing-only: same bytes per piece, but 8 rows x 128 B (whole, aligned cache lines) instead of 16 rows x 64 B
             const bf16_t* base = piece < 2 ? A + (size_t)(m0 + (wave * 2 + piece) * 8 + (lane >> 3)) * p.lda
                                            : W + (size_t)(n0 + (wave * 2 + piece - 2) * 8 + (lane >> 3)) * p.ldw;
-            dma16(base + (size_t)kt * BK + (lane & 7) * 8, sbase + (piece < 2 ? (wave * 2 + piece) * 1024 : A_BYTES + w_piece[piece - 2] * 1024));
+            dma16(base + (size_t)(kt % (nk / 2)) * (2 * BK) + (lane & 7) * 8, sbase + (piece < 2 ? (wave * 2 + piece) * 1024 : A_BYTES + w_piece[piece - 2] * 1024));
         } else if constexpr (MODE == GEMM_DENSE) {
             if (piece < 2)
                 dma16(a_src[piece] + (size_t)kt * BK, sbase + (wave * 2 + piece) * 1024);
@@ -200,6 +230,18 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
         for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto read_frags = [&](int kt, bf16x8 (&wf)[NI], bf16x8 (&af)[MI]) {
+        if constexpr (VAR == 20) {
+            // sub-step kt = 2t + ks of K-step t: tokens of this wave live in half-slab 2t + wm, its weight rows in 2t + (wn >> 1)
+            const int t2 = kt & ~1, ks = kt & 1;
+            const int chunk = ((4 * ks + fq) ^ (fr >> 1)) * 16;
+            const char* sa = smem + ((t2 + wm) % NSTAGE) * STAGE + fr * 128 + chunk;
+            const char* sw = smem + ((t2 + (wn >> 1)) % NSTAGE) * STAGE + A_BYTES + ((wn & 1) * 64 + fr) * 128 + chunk;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sw + i * 2048);
+#pragma unroll
+            for (int j = 0; j < MI; ++j) af[j] = *reinterpret_cast<const bf16x8*>(sa + j * 2048);
+            return;
+        }
         const char* sb = smem + (kt % NSTAGE) * STAGE;
 #pragma unroll
         for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + w_off + i * 1024);
@@ -224,12 +266,15 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    constexpr int D = NSTAGE - 1;  // K-steps in flight ahead of the one being consumed
+    constexpr int D = VAR == 20 ? 3 : NSTAGE - 1;  // ring units issued ahead of the one being consumed
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (d < nk) issue(d);
-    wait_pieces(min(D - 1, nk - 1));  // K-step 0 has landed for this wave
-    __builtin_amdgcn_s_barrier();     // ... and for every wave
+    if constexpr (VAR == 20)
+        wait_pieces(max(min(D - 1, nk - 1) - 1, 0));  // half-slabs 0 and 1 (K-step 0) have landed for this wave
+    else
+        wait_pieces(min(D - 1, nk - 1));  // K-step 0 has landed for this wave
+    __builtin_amdgcn_s_barrier();         // ... and for every wave
 
     if constexpr (VAR == 0 || VAR == 14) {
         // (VAR 14: timing-only, this schedule without the MFMAs)
@@ -272,7 +317,12 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
             }
             if (VAR != 11 || kt == 0) read_frags(kt, wf, af);
             // my pieces of K-step kt+1 must have landed before the barrier that precedes anybody's P_{kt+1}
-            wait_pieces(kt + 1 < nk ? min(kt + D, nk - 1) - (kt + 1) : 0);
+            if constexpr (VAR == 20) {
+                // sub-step 2t+1 is followed by K-step t+1 = half-slabs kt+1 and kt+2; after an even sub-step nothing new is needed
+                if ((kt & 1) && kt + 1 < nk) wait_pieces(max(min(kt + D, nk - 1) - (kt + 2), 0));
+            } else {
+                wait_pieces(kt + 1 < nk ? min(kt + D, nk - 1) - (kt + 1) : 0);
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -425,7 +475,7 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
 
 int g_gemm_variant = 1;  // tuning knob (f5_tuning_set("gemm_variant", v)): 0 = plain ring, 1 = ring + staggered wave groups, 10-12 ablations
 int g_gemm_group = 8;    // tuning knob ("gemm_group"): token tiles per L2 patch (1 = feature-tile-fastest order)
-int g_gemm_stages = 4;   // tuning knob ("gemm_stages"): LDS ring slots of the 256x256 tile (4 = 128 KiB, 5 = 160 KiB = the whole LDS)
+int g_gemm_stages = 5;   // tuning knob ("gemm_stages"): LDS ring slots of the 256x256 tile (4 = 128 KiB, 5 = 160 KiB = the whole LDS)
 
 template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmParams& p0, hipStream_t stream) {
     GemmParams p = p0;
@@ -436,13 +486,15 @@ template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmPa
     if constexpr (BN == 256) {
         if (g_gemm_variant == 0)
             hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 0, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
-        else if (g_gemm_variant >= 10 && EPI == EPI_GATE_T) {
+        else if (g_gemm_variant >= 10 && g_gemm_variant <= 14 && EPI == EPI_GATE_T) {
             if (g_gemm_variant == 10) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 10, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
             if (g_gemm_variant == 11) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 11, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
             if (g_gemm_variant == 12) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 12, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
             if (g_gemm_variant == 13) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 13, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
             if (g_gemm_variant == 14) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 14, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
-        } else if (g_gemm_variant == 3)
+        } else if (g_gemm_variant == 20 && MODE == GEMM_DENSE && p.K % 64 == 0)
+            hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI, 20, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
+        else if (g_gemm_variant == 3)
             hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 3, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
         else if (g_gemm_stages == 5)
             hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 1, 5>), grid, block, 0, stream, p, tiles_n, nblocks);

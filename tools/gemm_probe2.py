@@ -11,9 +11,9 @@ sites = {0: ("qkv  N3072 K1024", 2.0 * rows * 3072 * 1024), 1: ("ff1  N2048 K102
          2: ("ff2  N1024 K2048", 2.0 * rows * 1024 * 2048), 3: ("outp N1024 K1024", 2.0 * rows * 1024 * 1024)}
 res = {}
 for rnd in range(2):
-    for var in (1, 3):
+    for var in (1, 20):
         for st in (4, 5):
-            if var == 3 and st == 5:
+            if var == 20 and st == 5:
                 continue
             for pad in (0,):
                 for k, v in ((b"gemm_variant", var), (b"gemm_stages", st), (b"bench_pad_a", pad), (b"bench_pad_w", pad)):
