@@ -478,3 +478,22 @@ int launch_fill_f32(float* dst, size_t n, float v, hipStream_t stream) {
     F5_LAUNCH_CHECK();
     return 0;
 }
+
+// small host -> device float transfers as KERNEL ARGUMENTS (copied by the runtime at launch: no host-buffer lifetime or
+// pageable-memcpy staging question, and capturable)
+struct FloatPack {
+    float v[64];
+};
+__global__ void set_floats_kernel(float* __restrict__ dst, FloatPack pk, int n) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = pk.v[threadIdx.x];
+}
+int launch_set_floats(float* dst, const float* host_vals, int n, hipStream_t stream) {
+    for (int off = 0; off < n; off += 64) {
+        FloatPack pk;
+        const int m = n - off < 64 ? n - off : 64;
+        for (int i = 0; i < 64; ++i) pk.v[i] = i < m ? host_vals[off + i] : 0.f;
+        hipLaunchKernelGGL(set_floats_kernel, dim3(1), dim3(64), 0, stream, dst + off, pk, m);
+        F5_LAUNCH_CHECK();
+    }
+    return 0;
+}

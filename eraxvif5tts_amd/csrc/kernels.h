@@ -46,6 +46,8 @@ int launch_final_where(const float* cond, const float* x, const int32_t* lens, i
 // mask[b][n] = n < durations[b]
 int launch_len_mask(const int32_t* durations, int B, int N, uint8_t* mask, hipStream_t stream);
 int launch_fill_f32(float* dst, size_t n, float v, hipStream_t stream);
+// dst[0..n) = host_vals[0..n), passed through kernel arguments (no async-memcpy from pageable host memory)
+int launch_set_floats(float* dst, const float* host_vals, int n, hipStream_t stream);
 
 // ---- vocos.hip
 // im2col for Conv1d(k=7, pad=3): mel f32 [B, C, T] -> rows [B*T, Kp] (col = tap*C + c, zero padded to Kp)

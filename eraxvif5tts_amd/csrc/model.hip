@@ -688,8 +688,8 @@ extern "C" int f5_sample(f5_plan_t p, int B, int N, const float* cond, const int
         }
     }
     // stage inputs into plan-owned buffers (graph nodes have fixed addresses)
-    F5_HIP(hipMemcpyAsync(p->tvals, tv.data(), nev * sizeof(float), hipMemcpyHostToDevice, st));
-    F5_HIP(hipMemcpyAsync(p->coefs, cf.data(), nev * sizeof(float), hipMemcpyHostToDevice, st));
+    F5_TRY(launch_set_floats(p->tvals, tv.data(), nev, st));
+    F5_TRY(launch_set_floats(p->coefs, cf.data(), nev, st));
     F5_HIP(hipMemcpyAsync(p->cond_in, cond, state * sizeof(float), hipMemcpyDeviceToDevice, st));
     F5_HIP(hipMemcpyAsync(p->traj, y0, state * sizeof(float), hipMemcpyDeviceToDevice, st));
     F5_HIP(hipMemcpy2DAsync(p->text_in, (size_t)nt_eff * 4, text, (size_t)nt * 4, (size_t)nt_eff * 4, B, hipMemcpyDeviceToDevice, st));
