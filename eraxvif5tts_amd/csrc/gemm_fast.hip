@@ -135,7 +135,7 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
     //      2t (rows 0-127 of both operands) and 2t+1 (rows 128-255); it is consumed as two 32-deep sub-steps.
     [[maybe_unused]] const bf16_t* hs_a[2][2];  // [half r][piece j]
     [[maybe_unused]] const bf16_t* hs_w[2][2];
-    if constexpr (VAR == 20) {
+    if constexpr (VAR == 20 || VAR == 21) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int row = (wave * 2 + j) * 8 + (lane >> 3);          // row inside the half-slab operand (0..127)
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
     // piece ids of one K-step for this wave: 0,1 = activation pieces, 2.. = weight pieces
     auto issue_piece = [&](int kt, int piece) {
         char* sbase = smem + (kt % NSTAGE) * STAGE;
-        if constexpr (VAR == 20) {
+        if constexpr (VAR == 20 || VAR == 21) {
             // kt = half-slab index h: K range [64 * (h >> 1), +64), operand rows 128 * (h & 1) ..
             const int t = kt >> 1, r = kt & 1;
             if (piece < 2)
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
         for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto read_frags = [&](int kt, bf16x8 (&wf)[NI], bf16x8 (&af)[MI]) {
-        if constexpr (VAR == 20) {
+        if constexpr (VAR == 20 || VAR == 21) {
             // sub-step kt = 2t + ks of K-step t: tokens of this wave live in half-slab 2t + wm, its weight rows in 2t + (wn >> 1)
             const int t2 = kt & ~1, ks = kt & 1;
             const int chunk = ((4 * ks + fq) ^ (fr >> 1)) * 16;
@@ -266,11 +266,12 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    constexpr int D = VAR == 20 ? 3 : NSTAGE - 1;  // ring units issued ahead of the one being consumed
+    constexpr bool HS = (VAR == 20 || VAR == 21);  // half-slab ring (21: timing-only, without the MFMAs)
+    constexpr int D = HS ? 3 : NSTAGE - 1;  // ring units issued ahead of the one being consumed
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (d < nk) issue(d);
-    if constexpr (VAR == 20)
+    if constexpr (HS)
         wait_pieces(max(min(D - 1, nk - 1) - 1, 0));  // half-slabs 0 and 1 (K-step 0) have landed for this wave
     else
         wait_pieces(min(D - 1, nk - 1));  // K-step 0 has landed for this wave
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
             }
             if (VAR != 11 || kt == 0) read_frags(kt, wf, af);
             // my pieces of K-step kt+1 must have landed before the barrier that precedes anybody's P_{kt+1}
-            if constexpr (VAR == 20) {
+            if constexpr (HS) {
                 // sub-step 2t+1 is followed by K-step t+1 = half-slabs kt+1 and kt+2; after an even sub-step nothing new is needed
                 if ((kt & 1) && kt + 1 < nk) wait_pieces(max(min(kt + D, nk - 1) - (kt + 2), 0));
             } else {
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-            } else if constexpr (VAR != 12 && VAR != 13) {
+            } else if constexpr (VAR != 12 && VAR != 13 && VAR != 21) {
                 mma(wf, af);
             } else {
 #pragma unroll
@@ -494,6 +495,8 @@ template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmPa
             if (g_gemm_variant == 14) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 14, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
         } else if (g_gemm_variant == 20 && MODE == GEMM_DENSE && p.K % 64 == 0)
             hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI, 20, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
+        else if (g_gemm_variant == 21 && MODE == GEMM_DENSE && EPI == EPI_GATE_T && p.K % 64 == 0)
+            hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI_GATE_T, 21, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
         else if (g_gemm_variant == 3)
             hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 3, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
         else if (g_gemm_stages == 5)

@@ -158,3 +158,40 @@ def test_audio_front_end():
         audio.write_wav(f.name, trimmed.samples[:, 0] / 32768.0, sr)
         back, sr2, width = audio.read_wav(f.name)
         assert sr2 == sr and width == 2 and np.abs(back[:, 0] - trimmed.samples[:, 0]).max() <= 1
+
+
+def test_streaming_wire_format():
+    """44-byte header with unknown size, int16 PCM by truncation, reference-cache install/clear semantics."""
+    import struct
+    from eraxvif5tts_amd.streaming.wire import ReferenceCache, create_wave_header, pcm16_bytes, stream_audio
+    h = create_wave_header(24000)
+    assert len(h) == 44 and h[:4] == b"RIFF" and h[8:16] == b"WAVEfmt " and h[36:40] == b"data"
+    assert struct.unpack("<I", h[4:8])[0] == 36 and struct.unpack("<I", h[40:44])[0] == 0
+    assert struct.unpack("<HHIIHH", h[20:36]) == (1, 1, 24000, 48000, 2, 16)
+    h2 = create_wave_header(24000, data_size=4800)
+    assert struct.unpack("<I", h2[40:44])[0] == 4800 and struct.unpack("<I", h2[4:8])[0] == 36 + 4800
+    assert pcm16_bytes(np.array([0.0, 0.5, -0.5, 0.99999, -1.0], np.float32)) == np.array([0, 16383, -16383, 32766, -32767], np.int16).tobytes()
+
+    class FakeWrapper:
+        device, target_sample_rate = "cpu", 24000
+        ref_audio_processed = ref_text = ref_audio_len = None
+
+        def preprocess_reference(self, ref_audio_path, ref_text, clip_short):
+            if "bad" in ref_audio_path:
+                raise FileNotFoundError(ref_audio_path)
+            self.ref_audio_processed, self.ref_text, self.ref_audio_len = torch.ones(1, 2560), ref_text + ". ", 10
+            return self.ref_audio_processed, self.ref_text
+
+        def generate(self, text, return_numpy, **kw):
+            assert self.ref_text == "hi. " and self.ref_audio_len == 10
+            return np.full(len(text), 0.25, np.float32), 24000
+
+    m, cache = FakeWrapper(), ReferenceCache()
+    assert cache.add(m, "male", "ok.wav", "hi")["loaded"] is True and m.ref_text is None
+    assert cache.add(m, "ghost", "bad.wav")["loaded"] is False
+    with pytest.raises(LookupError, match="not ready"):
+        next(stream_audio(m, cache, "ghost", ["x"]))
+    parts = list(stream_audio(m, cache, "male", ["abc", "  ", "hello.."]))
+    assert parts[0] == h and len(parts) == 3
+    assert parts[1] == np.full(3, 8191, np.int16).tobytes() and len(parts[2]) == 2 * len("hello.")
+    assert m.ref_text is None and m.ref_audio_processed is None  # state cleared after the request

@@ -6,9 +6,9 @@ sys.path.insert(0, ".")
 from eraxvif5tts_amd import _lib
 _lib.require_gpu()
 lib = _lib.load()
-names = {1: "full", 10: "no DMA in loop", 11: "fragments read once", 12: "no MFMA", 13: "no MFMA, 128-B-row pieces", 0: "plain ring", 14: "plain ring, no MFMA"}
+names = {1: "full", 10: "no DMA in loop", 11: "fragments read once", 12: "no MFMA", 13: "no MFMA, 128-B-row pieces", 0: "plain ring", 14: "plain ring, no MFMA", 20: "half-slab ring", 21: "half-slab ring, no MFMA"}
 for rnd in range(2):
-    for v in (12, 13):
+    for v in (1, 12, 20, 21):
         _lib.check(lib.f5_tuning_set(b"gemm_variant", v))
         out = []
         for site in (2, 3):
