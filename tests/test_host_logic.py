@@ -168,8 +168,9 @@ def test_streaming_wire_format():
     assert len(h) == 44 and h[:4] == b"RIFF" and h[8:16] == b"WAVEfmt " and h[36:40] == b"data"
     assert struct.unpack("<I", h[4:8])[0] == 36 and struct.unpack("<I", h[40:44])[0] == 0
     assert struct.unpack("<HHIIHH", h[20:36]) == (1, 1, 24000, 48000, 2, 16)
-    h2 = create_wave_header(24000, data_size=4800)
-    assert struct.unpack("<I", h2[40:44])[0] == 4800 and struct.unpack("<I", h2[4:8])[0] == 36 + 4800
+    # the reference's data_size > 0 branch goes through the same wave.open/close: close() re-patches the sizes to the (zero)
+    # bytes actually written, so the header is identical -- reproduced as is
+    assert create_wave_header(24000, data_size=4800) == h
     assert pcm16_bytes(np.array([0.0, 0.5, -0.5, 0.99999, -1.0], np.float32)) == np.array([0, 16383, -16383, 32766, -32767], np.int16).tobytes()
 
     class FakeWrapper:
