@@ -169,21 +169,28 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel: fused QKV projection (29 % of the FLOPs, one shape per launch)
         rows = 2 * B * N if args.cfg >= 1e-5 else B * N
-        ms = C.c_float(0.0)
         flops = 2.0 * rows * (3 * 16 * 64) * 1024
-        kernel_kind = 1
-        rc = lib.f5_bench_gemm_site(kernel_kind, 0, rows, N, 1024, 16, 2048, 10, C.byref(ms), _lib.stream_ptr())
-        if rc != 0:
-            kernel_kind = 0
-            _lib.check(lib.f5_bench_gemm_site(0, 0, rows, N, 1024, 16, 2048, 3, C.byref(ms), _lib.stream_ptr()), "bench_gemm_site")
+        # in situ: one extra eager sample() with a HIP event pair around every fused-QKV launch (22 blocks x nfe evaluations),
+        # on the stream the kernels run on; this is the same launch rocprofv3 averages in profiles/
+        plan = model.plan(B, N, nfe)
+        ms, cnt = C.c_float(0.0), C.c_int(0)
+        _lib.check(lib.f5_plan_timing_begin(plan, BASE_ARCH["depth"] * nfe), "timing_begin")
+        cfm.sample(cond=cond, text=text, duration=duration, lens=lens, steps=nfe, cfg_strength=args.cfg, sway_sampling_coef=-1.0, seed=0,
+                   return_trajectory=False, use_graph=False)
+        _lib.check(lib.f5_plan_timing_end(plan, C.byref(ms), C.byref(cnt), _lib.stream_ptr()), "timing_end")
         achieved = flops / (ms.value * 1e-3) / 1e12
+        # isolated: back-to-back launches of the same kernel on cold operands (f5_bench_gemm_site), for reference
+        iso = C.c_float(0.0)
+        iso_ok = lib.f5_bench_gemm_site(1, 0, rows, N, 1024, 16, 2048, 10, C.byref(iso), _lib.stream_ptr()) == 0
         result["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
                               # HBM-side bytes per launch from the rocprofv3 PMC passes recorded in profiles/r1_04_* (FETCH_SIZE x 2 on gfx950
                               # + WRITE_SIZE); only meaningful for the default C2 shape, null otherwise
                               "traffic": QKV_TRAFFIC_BYTES if (rows == 65536 and N == 1024) else None,
-                              "kernel": ("gemm_fast" if kernel_kind == 1 else "gemm_tile") + "<bf16, QKV+RoPE epilogue>",
-                              "launch": f"M={rows} N=3072 K=1024, {flops / 1e9:.1f} GFLOP, {ms.value:.4f} ms/launch (HIP events, 10 launches)"}
+                              "kernel": "gemm_fast_kernel<256,128,DENSE,QKV+RoPE epilogue>",
+                              "launch": f"M={rows} N=3072 K=1024, {flops / 1e9:.1f} GFLOP, {ms.value:.4f} ms mean over {cnt.value} launches inside an "
+                                        f"eager sample() (HIP event pairs on the launch stream)",
+                              "isolated_tflops": round(flops / (iso.value * 1e-3) / 1e12, 2) if iso_ok else None}
         # whole-loop MFMA fraction from the algorithmic FLOPs of SURVEY.md 8(d)
         per_token = 378.9e6 + 90112.0 * N
         total_flops = per_token * B * N * (2 if args.cfg >= 1e-5 else 1) * nfe * args.steps * world

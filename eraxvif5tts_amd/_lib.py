@@ -43,6 +43,8 @@ _PROTOS = {
     "f5_sample": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _F, _I, _P, _P, _I, _P]),
     "f5_text_embed": (_I, [_P, _I, _I, _P, _I, _I, _P, _P]),
     "f5_dit_forward": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
+    "f5_plan_timing_begin": (_I, [_P, _I]),
+    "f5_plan_timing_end": (_I, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int), _P]),
     "f5_plan_set_tap": (_I, [_P, C.c_char_p, _P]),
     "f5_plan_set_option": (_I, [_P, C.c_char_p, _I]),
     "f5_op_linear": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P]),

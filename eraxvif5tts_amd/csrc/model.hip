@@ -72,6 +72,10 @@ struct f5_plan_s {
     std::map<std::string, float*> taps;
     std::vector<GraphEntry> graphs;
     hipStream_t cap_stream = nullptr;  // capture happens on a private stream (the caller's may be the legacy null stream)
+    // in-situ timing of the dominant kernel (fused QKV GEMM): HIP event pairs around every launch of an eager sample()
+    bool timing = false;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
 };
 
 // ----------------------------------------------------------------------------- model
@@ -394,6 +398,7 @@ extern "C" int f5_plan_destroy(f5_plan_t p) {
         if (g.graph) (void)hipGraphDestroy(g.graph);
     }
     if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
+    for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     delete p;
     return 0;
 }
@@ -412,6 +417,37 @@ extern "C" int f5_plan_set_option(f5_plan_t p, const char* key, int value) {
         if (g.graph) (void)hipGraphDestroy(g.graph);
     }
     p->graphs.clear();
+    return 0;
+}
+
+extern "C" int f5_plan_timing_begin(f5_plan_t p, int max_launches) {
+    if (!p || max_launches <= 0) return f5_fail(F5_EINVAL, "bad argument");
+    for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+    p->ev.assign((size_t)max_launches * 2, nullptr);
+    for (auto& e : p->ev) F5_HIP(hipEventCreate(&e));
+    p->ev_used = 0;
+    p->timing = true;
+    return 0;
+}
+
+extern "C" int f5_plan_timing_end(f5_plan_t p, float* avg_ms, int* launches, f5_stream_t stream) {
+    if (!p || !avg_ms || !launches) return f5_fail(F5_EINVAL, "null argument");
+    p->timing = false;
+    F5_HIP(hipStreamSynchronize((hipStream_t)stream));
+    double sum = 0.0;
+    int n = 0;
+    for (size_t i = 0; i + 1 < p->ev_used; i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]) == hipSuccess) {
+            sum += ms;
+            ++n;
+        }
+    }
+    for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+    p->ev.clear();
+    p->ev_used = 0;
+    *avg_ms = n ? (float)(sum / n) : 0.f;
+    *launches = n;
     return 0;
 }
 
@@ -545,7 +581,14 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         g.A = p->hT; g.lda = D; g.W = b.w_qkv; g.ldw = D; g.M = rows; g.N = 3 * inner; g.K = D;
         g.bias = b.b_qkv; g.out_t = p->qkv; g.ldo = 3 * inner; g.rows_per_batch = N;
         g.rope = p->rope; g.rope_inner = inner; g.rope_heads = m->rope_heads;
-        F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_ROPE_T, st));
+        if (p->timing && p->ev_used + 2 <= p->ev.size()) {
+            (void)hipEventRecord(p->ev[p->ev_used], st);
+            F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_ROPE_T, st));
+            (void)hipEventRecord(p->ev[p->ev_used + 1], st);
+            p->ev_used += 2;
+        } else {
+            F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_ROPE_T, st));
+        }
         {
             int kind = 0;
             if (p->attn_kernel != 0 && attention_fast_supported(P, N, c.heads)) kind = 1;
@@ -697,7 +740,7 @@ extern "C" int f5_sample(f5_plan_t p, int B, int N, const float* cond, const int
     if (durations) F5_HIP(hipMemcpyAsync(p->dur_in, durations, B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
 
     SampleArgs a{B, N, nt_eff, steps, ode_method, cfg_strength >= 1e-5f ? 1 : 0, durations ? 1 : 0, cfg_strength};  // cfm.py:167
-    if (use_graph && p->taps.empty()) {
+    if (use_graph && p->taps.empty() && !p->timing) {
         GraphEntry* ge = nullptr;
         for (auto& g : p->graphs)
             if (g.B == B && g.N == N && g.nt == a.nt && g.steps == steps && g.method == ode_method && g.cfg_on == a.cfg_on &&

@@ -122,6 +122,11 @@ int f5_dit_forward(f5_plan_t p, int B, int N, const float* x, const float* cond,
  * (converted to f32, row-major [rows, cols]) into `dst` (dev f32).  Names: "t_emb", "input_embed",
  * "blk<i>.n1", "blk<i>.attn", "blk<i>.out", "final_norm".  Pass dst = NULL to clear all taps. */
 int f5_plan_set_tap(f5_plan_t p, const char* stage, float* dst);
+/* in-situ timing of the dominant kernel: between begin and end, every fused-QKV GEMM launch of (eager) f5_sample /
+ * f5_dit_forward calls on this plan is bracketed by a HIP event pair on the caller's stream; end synchronises the stream and
+ * returns the mean device time per launch.  Used by bench.py for roofline.achieved. */
+int f5_plan_timing_begin(f5_plan_t p, int max_launches);
+int f5_plan_timing_end(f5_plan_t p, float* avg_ms, int* launches, f5_stream_t stream);
 /* kernel selection for A/B runs: key "gemm_kernel" / "attn_kernel"; value 0 = reference tile kernels, 1 or -1 = tuned
  * kernels wherever they support the problem (default).  Drops any captured graphs. */
 int f5_plan_set_option(f5_plan_t p, const char* key, int value);
