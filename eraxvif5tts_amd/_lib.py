@@ -84,6 +84,11 @@ def load(build_if_missing: bool = False):
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
     _lib = lib
+    # developer knobs for A/B runs: F5HIP_TUNING="gemm_nt=33,attn_variant=1" -> f5_tuning_set(key, value)
+    for item in filter(None, os.environ.get("F5HIP_TUNING", "").split(",")):
+        key, _, val = item.partition("=")
+        if lib.f5_tuning_set(key.strip().encode(), int(val)) != 0:
+            raise F5HipError(f"F5HIP_TUNING: {lib.f5_last_error().decode('utf-8', 'replace')}")
     return lib
 
 

@@ -468,6 +468,27 @@ int launch_len_mask(const int32_t* durations, int B, int N, uint8_t* mask, hipSt
     return 0;
 }
 
+// rowbits[(m / 128) * 16 + (m % 16)] bit ((m % 128) / 16) = mask[m] != 0: the eight rows one lane of the tuned GEMM's epilogue owns
+// inside a 128-row wave tile, in one byte (gemm.h: GemmParams::rowbits)
+__global__ __launch_bounds__(256) void rowbits_kernel(const uint8_t* __restrict__ mask, int rows, uint8_t* __restrict__ bits) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ((rows + 127) >> 7) * 16) return;
+    const int base = (i >> 4) * 128 + (i & 15);
+    unsigned b = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int m = base + 16 * j;
+        if (m < rows && mask[m]) b |= 1u << j;
+    }
+    bits[i] = (uint8_t)b;
+}
+int launch_rowbits(const uint8_t* mask, int rows, uint8_t* bits, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(rowbits_kernel, dim3(cdiv(cdiv(rows, 128) * 16, 256)), dim3(256), 0, stream, mask, rows, bits);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
 __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ dst, size_t n, float v) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = v;

@@ -40,12 +40,15 @@ struct GemmParams {
     int gate_bstride;
     int rows_per_batch;      // sequence length N_seq: b(m) = m / rows_per_batch, position = m % rows_per_batch
     const uint8_t* rowmask;  // [M] or null
+    const uint8_t* rowbits;  // optional transposed form of rowmask for the tuned kernel's epilogue (launch_rowbits): byte [m/128][m%16], bit (m%128)/16
     const float* rope;       // [N_seq][32][2] (cos, sin)
     int rope_inner;          // heads * 64
     int rope_heads;          // heads that receive RoPE
     // CONV31: channels per group (dim/16) and the padded input-channel window one 64-channel output tile reads
     int conv_cg, conv_win;
     int tile_group;  // tuned kernel: token tiles per L2 patch (set by the launcher)
+    int nt_store;    // tuned kernel, lean epilogue: non-temporal stores (set by the launcher)
+    int lean_epi;    // tuned kernel: whole tiles take the lean epilogue (set by the launcher; 0 = always the generic one)
 };
 
 // kernel_kind: 0 = reference tile kernel (any shape), 1 = tuned 256x256 LDS-DMA bf16 kernel

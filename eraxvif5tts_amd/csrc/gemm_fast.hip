@@ -76,20 +76,25 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-    // XCD-aware bijective remap (blocks b and b+8 share an XCD): give each XCD a contiguous band of tiles
-    const int bid = blockIdx.x;
-    const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7;
-    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    // inside an XCD band, walk groups of `gm` token tiles x all feature tiles with the token tile fastest: the ~32 tiles an
+    // XCD-aware bijective remap (blocks b and b+8 share an XCD): give each XCD a contiguous band of tiles.
+    // Inside an XCD band, walk groups of `gm` token tiles x all feature tiles with the token tile fastest: the ~32 tiles an
     // XCD runs together then form a squarer (gm x 32/gm) patch of the output, which minimises the distinct operand slices
     // its L2 has to hold per K-step
-    const int gm = p.tile_group > 0 ? p.tile_group : 1;
-    const int tiles_m_all = nblocks / tiles_n;
-    const int grp = swz / (gm * tiles_n);
-    const int gsz = min(gm, tiles_m_all - grp * gm);  // last group may be short
-    const int rin = swz - grp * gm * tiles_n;
-    const int tile_n = rin / gsz, tile_m = grp * gm + (rin - tile_n * gsz);
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    auto tile_mn = [&](int bid, int& tm0, int& tn0) {
+        const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7;
+        const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int gm = p.tile_group > 0 ? p.tile_group : 1;
+        const int tiles_m_all = nblocks / tiles_n;
+        const int grp = swz / (gm * tiles_n);
+        const int gsz = min(gm, tiles_m_all - grp * gm);  // last group may be short
+        const int rin = swz - grp * gm * tiles_n;
+        const int tile_n = rin / gsz, tile_m = grp * gm + (rin - tile_n * gsz);
+        tm0 = tile_m * BM;
+        tn0 = tile_n * BN;
+    };
+    constexpr bool PERSIST = VAR >= 30;  // (31 / 32: timing-only ablations without the epilogue's stores / without the epilogue)  // persistent grid: a block walks tiles bid, bid + gridDim.x, ... and prefetches across tile boundaries
+    int m0, n0;                          // tile being computed (epilogue side)
+    tile_mn(blockIdx.x, m0, n0);
 
     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
     const bf16_t* W = reinterpret_cast<const bf16_t*>(p.W);
@@ -100,31 +105,35 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
     const bf16_t* a_src[2];
     int a_pos[2];
     bool a_ok[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        int gm = m0 + (wave * 2 + j) * 16 + prow;
-        a_ok[j] = gm < p.M;
-        if (gm >= p.M) gm = p.M - 1;
-        a_pos[j] = 0;
-        if constexpr (MODE == GEMM_DENSE) {
-            if (p.a_row_mod > 0) gm %= p.a_row_mod;
-        } else {
-            a_pos[j] = gm % p.rows_per_batch;
-        }
-        a_src[j] = A + (size_t)gm * p.lda + plc * 8;
-    }
     const bf16_t* w_src[WJ];
     int w_piece[WJ];
 #pragma unroll
-    for (int j = 0; j < WJ; ++j) {
-        w_piece[j] = (wave * WJ + j) % (BN / 16);
-        int gn = n0 + w_piece[j] * 16 + prow;
-        if (gn >= p.N) gn = p.N - 1;
-        if constexpr (MODE == GEMM_DENSE)
-            w_src[j] = W + (size_t)gn * p.ldw + plc * 8;
-        else
-            w_src[j] = W + (size_t)gn * p.conv_win + plc * 8;
-    }
+    for (int j = 0; j < WJ; ++j) w_piece[j] = (wave * WJ + j) % (BN / 16);
+    auto setup_src = [&](int sm0, int sn0) {  // DMA sources of tile (sm0, sn0)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int gm = sm0 + (wave * 2 + j) * 16 + prow;
+            a_ok[j] = gm < p.M;
+            if (gm >= p.M) gm = p.M - 1;
+            a_pos[j] = 0;
+            if constexpr (MODE == GEMM_DENSE) {
+                if (p.a_row_mod > 0) gm %= p.a_row_mod;
+            } else {
+                a_pos[j] = gm % p.rows_per_batch;
+            }
+            a_src[j] = A + (size_t)gm * p.lda + plc * 8;
+        }
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            int gn = sn0 + w_piece[j] * 16 + prow;
+            if (gn >= p.N) gn = p.N - 1;
+            if constexpr (MODE == GEMM_DENSE)
+                w_src[j] = W + (size_t)gn * p.ldw + plc * 8;
+            else
+                w_src[j] = W + (size_t)gn * p.conv_win + plc * 8;
+        }
+    };
+    setup_src(m0, n0);
     const int cslices = MODE == GEMM_CONV31 ? p.conv_win / BK : 1;
     const int nk = MODE == GEMM_CONV31 ? 31 * cslices : p.K / BK;
     const int win0 = MODE == GEMM_CONV31 ? (n0 / p.conv_cg) * p.conv_cg : 0;
@@ -154,8 +163,8 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
     }
 
     // piece ids of one K-step for this wave: 0,1 = activation pieces, 2.. = weight pieces
-    auto issue_piece = [&](int kt, int piece) {
-        char* sbase = smem + (kt % NSTAGE) * STAGE;
+    auto issue_piece = [&](int slot, int kt, int piece) {
+        char* sbase = smem + slot * STAGE;
         if constexpr (VAR == 20 || VAR == 21) {
             // kt = half-slab index h: K range [64 * (h >> 1), +64), operand rows 128 * (h & 1) ..
             const int t = kt >> 1, r = kt & 1;
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
     };
     auto issue = [&](int kt) {
 #pragma unroll
-        for (int pc = 0; pc < PPW; ++pc) issue_piece(kt, pc);
+        for (int pc = 0; pc < PPW; ++pc) issue_piece(kt % NSTAGE, kt, pc);
     };
 
     // ---- fragment read offsets (bytes inside a stage)
@@ -197,37 +206,49 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
     const int a_off = (wm * WM + fr) * 64 + c0;
     const int w_off = A_BYTES + (wn * WN + fr) * 64 + c0;
 
-    // ---- epilogue operands that do not depend on the token are fetched now, so their latency hides under the main loop
+    // ---- epilogue operands that do not depend on the token are fetched at the start of a tile, so their latency hides under the main loop
     int ncol[NI];
     bool okn[NI];
     f32x4 bias4[NI];
     [[maybe_unused]] f32x4 gate4[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int n = n0 + wn * WN + i * 16 + 4 * fq;
-        okn[i] = n + 3 < p.N;  // N % 4 == 0: a lane's 4 features are valid together
-        ncol[i] = okn[i] ? n : 0;
-        bias4[i] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ncol[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (EPI == EPI_GATE_T || EPI == EPI_RESID)
-            gate4[i] = (p.gate && p.gate_bstride == 0) ? *reinterpret_cast<const f32x4*>(p.gate + ncol[i]) : f32x4{1.f, 1.f, 1.f, 1.f};
-    }
-    // fused QKV projection: a wave's 64 features are exactly one head of q, k or v -> RoPE applies to the whole wave tile or not at all
     [[maybe_unused]] bool rope_wave = false;
-    if constexpr (EPI == EPI_ROPE_T) {
-        const int nw = n0 + wn * WN;
-        const int part = nw / p.rope_inner;
-        rope_wave = part < 2 && ((nw - part * p.rope_inner) >> 6) < p.rope_heads;
-    }
-
-    // 16-byte paired stores: after pair_swap a lane in 16-lane row r owns features (r&1 ? tile i+1 : tile i) * 16 + 8*(r>>1) .. +7
-    const bool wide_ok = (n0 + wn * WN + WN <= p.N) && (p.ldo & 7) == 0;
-    const int nwide = n0 + wn * WN + 16 * (fq & 1) + 8 * (fq >> 1);
+    bool wide_ok;
+    int nwide;
+    [[maybe_unused]] unsigned keepbits = 0xffu;  // lean epilogue: bit j = row (j * 16 + fr) of this wave's token rows is kept
+    auto prep_epilogue = [&]() {
+        if constexpr (EPI == EPI_GATE_T) {
+            const int mw = m0 + wm * WM;
+            if (p.rowmask && p.rowbits && mw < p.M) keepbits = (unsigned)p.rowbits[(mw >> 7) * 16 + fr] >> ((mw & 127) >> 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int n = n0 + wn * WN + i * 16 + 4 * fq;
+            okn[i] = n + 3 < p.N;  // N % 4 == 0: a lane's 4 features are valid together
+            ncol[i] = okn[i] ? n : 0;
+            bias4[i] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ncol[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == EPI_GATE_T || EPI == EPI_RESID)
+                gate4[i] = (p.gate && p.gate_bstride == 0) ? *reinterpret_cast<const f32x4*>(p.gate + ncol[i]) : f32x4{1.f, 1.f, 1.f, 1.f};
+        }
+        // fused QKV projection: a wave's 64 features are exactly one head of q, k or v -> RoPE applies to the whole wave tile or not at all
+        if constexpr (EPI == EPI_ROPE_T) {
+            const int nw = n0 + wn * WN;
+            const int part = nw / p.rope_inner;
+            rope_wave = part < 2 && ((nw - part * p.rope_inner) >> 6) < p.rope_heads;
+        }
+        // 16-byte paired stores: after pair_swap a lane in 16-lane row r owns features (r&1 ? tile i+1 : tile i) * 16 + 8*(r>>1) .. +7
+        wide_ok = (n0 + wn * WN + WN <= p.N) && (p.ldo & 7) == 0;
+        nwide = n0 + wn * WN + 16 * (fq & 1) + 8 * (fq >> 1);
+    };
+    prep_epilogue();
 
     f32x4 acc[NI][MI];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
 
     auto read_frags = [&](int kt, bf16x8 (&wf)[NI], bf16x8 (&af)[MI]) {
         if constexpr (VAR == 20 || VAR == 21) {
@@ -242,7 +263,7 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
             for (int j = 0; j < MI; ++j) af[j] = *reinterpret_cast<const bf16x8*>(sa + j * 2048);
             return;
         }
-        const char* sb = smem + (kt % NSTAGE) * STAGE;
+        const char* sb = smem + (PERSIST ? kt : kt % NSTAGE) * STAGE;  // PERSIST: the caller passes the ring slot
 #pragma unroll
         for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + w_off + i * 1024);
 #pragma unroll
@@ -266,100 +287,17 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    constexpr bool HS = (VAR == 20 || VAR == 21);  // half-slab ring (21: timing-only, without the MFMAs)
-    constexpr int D = HS ? 3 : NSTAGE - 1;  // ring units issued ahead of the one being consumed
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (d < nk) issue(d);
-    if constexpr (HS)
-        wait_pieces(max(min(D - 1, nk - 1) - 1, 0));  // half-slabs 0 and 1 (K-step 0) have landed for this wave
-    else
-        wait_pieces(min(D - 1, nk - 1));  // K-step 0 has landed for this wave
-    __builtin_amdgcn_s_barrier();         // ... and for every wave
-
-    if constexpr (VAR == 0 || VAR == 14) {
-        // (VAR 14: timing-only, this schedule without the MFMAs)
-        // ---- plain ring: every wave does {refill, fragment reads, MFMAs} per K-step, one barrier per K-step
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt + D < nk) issue(kt + D);  // refills slot (kt-1) % NSTAGE: its readers passed the previous barrier
-            bf16x8 wf[NI], af[MI];
-            read_frags(kt, wf, af);
-            if constexpr (VAR == 0) {
-                mma(wf, af);
-            } else {
-#pragma unroll
-                for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(wf[i]));
-#pragma unroll
-                for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(af[j]));
-            }
-            if (kt + 1 < nk) {
-                wait_pieces(min(kt + D, nk - 1) - (kt + 1));
-                __builtin_amdgcn_s_barrier();
-            }
-        }
-    } else {
-        // ---- ring + staggered wave groups (the two waves that share a SIMD never run the same phase together):
-        //   every wave alternates  P_k: {refill slot (k-1) % NSTAGE by DMA, ds_read the fragments of K-step k, counted vmcnt
-        //   for K-step k+1}  |barrier|  C_k: {32 MFMAs}  |barrier| ...; waves 4-7 run one barrier interval behind waves 0-3,
-        //   so in every interval one group feeds the matrix pipe while its SIMD partners do their LDS/DMA work.
-        // VAR >= 10: timing-only ablations (results are wrong by construction): 10 no DMA in the loop, 11 fragments read once, 12 no MFMA
-        const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
-        if (late) __builtin_amdgcn_s_barrier();
-        bf16x8 wf[NI], af[MI];
-        for (int kt = 0; kt < nk; ++kt) {
-            // -- P_kt.  Slot (kt-1) % NSTAGE is free: both groups retired their reads of it (lgkmcnt(0) below) at least one barrier ago.
-            if constexpr (VAR == 3) {
-                if (kt + D < nk) {
-#pragma unroll
-                    for (int pc = 0; pc < PPW / 2; ++pc) issue_piece(kt + D, pc);
-                }
-            } else {
-                if (VAR != 10 && kt + D < nk) issue(kt + D);
-            }
-            if (VAR != 11 || kt == 0) read_frags(kt, wf, af);
-            // my pieces of K-step kt+1 must have landed before the barrier that precedes anybody's P_{kt+1}
-            if constexpr (HS) {
-                // sub-step 2t+1 is followed by K-step t+1 = half-slabs kt+1 and kt+2; after an even sub-step nothing new is needed
-                if ((kt & 1) && kt + 1 < nk) wait_pieces(max(min(kt + D, nk - 1) - (kt + 2), 0));
-            } else {
-                wait_pieces(kt + 1 < nk ? min(kt + D, nk - 1) - (kt + 1) : 0);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            // -- C_kt
-            __builtin_amdgcn_s_setprio(1);
-            if constexpr (VAR == 3) {
-                // second half of the DMA pieces rides in the MFMA phase (balances the two barrier intervals)
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-#pragma unroll
-                    for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
-                    if (i == NI / 2 - 1 && kt + D < nk) {
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int pc = PPW / 2; pc < PPW; ++pc) issue_piece(kt + D, pc);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            } else if constexpr (VAR != 12 && VAR != 13 && VAR != 21) {
-                mma(wf, af);
-            } else {
-#pragma unroll
-                for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(wf[i]));
-#pragma unroll
-                for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(af[j]));
-            }
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-        }
-        if (!late) __builtin_amdgcn_s_barrier();  // same barrier count for both groups
-    }
-
     // ---------------------------------------------------------------- epilogue (store-only wherever the call site allows)
     // Loads (row mask, RoPE table, addend / residual) are issued in groups BEFORE any store of the group: vmcnt retires
     // in order, so a load issued behind a store would also wait for that store's round trip.
+    auto generic_epilogue = [&]() {
+    if constexpr (VAR == 32 || VAR == 15) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
     constexpr int JG = (EPI == EPI_RESID || EPI == EPI_GATE_T) ? 2 : (MI >= 4 ? 4 : MI);  // token tiles per load group (register budget)
     static_for<MI / JG>([&](auto gc) {
         constexpr int j0 = decltype(gc)::value * JG;
@@ -446,7 +384,10 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
                     static_for<NI / 2>([&](auto hc) {
                         constexpr int i = decltype(hc)::value * 2;
                         const u32x4 q = pair_swap(to_bf16x4(vals[i]), to_bf16x4(vals[i + 1]));
-                        if (okm[jj]) *reinterpret_cast<u32x4*>(orow + nwide + 32 * (i / 2)) = q;
+                        if constexpr (VAR == 31)
+                            asm volatile("" ::"v"(q));
+                        else if (okm[jj])
+                            *reinterpret_cast<u32x4*>(orow + nwide + 32 * (i / 2)) = q;
                     });
                 } else {
                     static_for<NI>([&](auto ic) {
@@ -472,33 +413,296 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
             }
         });
     });
+    };
+
+    // ---- lean epilogue for whole tiles (the hot case): no bounds logic, one base pointer, packed fp32 math, software-pipelined
+    //      RoPE table loads, row mask from one preloaded byte.  The generic epilogue below costs ~5x the instructions.
+    [[maybe_unused]] auto lean_epilogue = [&](auto actc) {
+        constexpr int ACT = decltype(actc)::value;
+        bf16_t* orow = reinterpret_cast<bf16_t*>(p.out_t) + (size_t)(m0 + wm * WM + fr) * p.ldo + nwide;
+        const size_t jstride = (size_t)16 * p.ldo;
+        [[maybe_unused]] f32x4 rp[2][NI];
+        [[maybe_unused]] int pos0 = 0;
+        auto load_rope = [&](auto jc, f32x4 (&dst)[NI]) {
+            constexpr int j = decltype(jc)::value;
+            int pos = pos0 + 16 * j;
+            pos -= pos >= p.rows_per_batch ? p.rows_per_batch : 0;  // rows_per_batch >= WM (checked by the caller of the lean path)
+            const float* t = p.rope + (size_t)pos * 64 + 4 * fq;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) dst[i] = *reinterpret_cast<const f32x4*>(t + 16 * i);
+        };
+        if constexpr (EPI == EPI_ROPE_T) {
+            pos0 = (m0 + wm * WM + fr) % p.rows_per_batch;
+            if (rope_wave) load_rope(std::integral_constant<int, 0>{}, rp[0]);
+        }
+        static_for<MI>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (EPI == EPI_ROPE_T && j + 1 < MI) {
+                if (rope_wave) load_rope(std::integral_constant<int, j + 1>{}, rp[(j + 1) & 1]);
+            }
+            f32x4 vals[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                f32x4 v = acc[i][j] + bias4[i];
+                if constexpr (ACT == ACT_GELU_TANH) {
+                    constexpr float a = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
+                    const f32x4 u = v * __builtin_elementwise_fma(v * v, f32x4{a * 0.044715f, a * 0.044715f, a * 0.044715f, a * 0.044715f}, f32x4{a, a, a, a});
+                    f32x4 d;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[e] = __builtin_amdgcn_exp2f(u[e]);
+                    d = d + 1.0f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[e] = __builtin_amdgcn_rcpf(d[e]);
+                    v = v * d;
+                } else if constexpr (ACT == ACT_MISH) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fast_mish(v[e]);
+                }
+                if constexpr (EPI == EPI_GATE_T) v = v * gate4[i];
+                if constexpr (EPI == EPI_ROPE_T) {
+                    if (rope_wave) {
+                        const f32x4 cs = rp[j & 1][i];
+                        v = f32x4{v[0] * cs[0] - v[1] * cs[1], v[1] * cs[0] + v[0] * cs[1], v[2] * cs[2] - v[3] * cs[3], v[3] * cs[2] + v[2] * cs[3]};
+                    }
+                }
+                vals[i] = v;
+            }
+            u32x4 q0 = pair_swap(to_bf16x4(vals[0]), to_bf16x4(vals[1]));
+            u32x4 q1 = pair_swap(to_bf16x4(vals[2]), to_bf16x4(vals[3]));
+            if constexpr (EPI == EPI_GATE_T) {
+                const bool keep = (keepbits >> j) & 1u;
+                q0 = keep ? q0 : u32x4{0u, 0u, 0u, 0u};
+                q1 = keep ? q1 : u32x4{0u, 0u, 0u, 0u};
+            }
+            bf16_t* o = orow + j * jstride;
+            if constexpr (VAR == 16) {  // timing-only: the lean epilogue without its stores
+                asm volatile("" ::"v"(q0), "v"(q1), "v"(o));
+            } else if (VAR == 17 || p.nt_store) {  // streaming stores: the output tile does not displace the operand slices in L2
+                __builtin_nontemporal_store(q0, reinterpret_cast<u32x4*>(o));
+                __builtin_nontemporal_store(q1, reinterpret_cast<u32x4*>(o + 32));
+            } else {
+                *reinterpret_cast<u32x4*>(o) = q0;
+                *reinterpret_cast<u32x4*>(o + 32) = q1;
+            }
+        });
+    };
+    // whole tile + the operand forms the lean epilogue assumes; anything else takes the generic path
+    [[maybe_unused]] auto lean_ok = [&]() {
+        if constexpr (!(EPI == EPI_STORE_T || EPI == EPI_GATE_T || EPI == EPI_ROPE_T) || VAR == 31 || VAR == 32 || VAR == 15) return false;
+        bool ok = m0 + BM <= p.M && n0 + BN <= p.N && (p.ldo & 7) == 0 && p.bias != nullptr && p.act != ACT_GELU_ERF;
+        if constexpr (EPI == EPI_GATE_T) ok = ok && p.gate_bstride == 0 && (!p.rowmask || p.rowbits);
+        if constexpr (EPI == EPI_ROPE_T) ok = ok && p.rows_per_batch >= WM;
+        return ok;
+    };
+    auto epilogue = [&]() {
+        if constexpr (EPI == EPI_STORE_T || EPI == EPI_GATE_T || EPI == EPI_ROPE_T) {
+            if (p.lean_epi && lean_ok()) {
+                if (p.act == ACT_GELU_TANH)
+                    lean_epilogue(std::integral_constant<int, ACT_GELU_TANH>{});
+                else if (p.act == ACT_MISH)
+                    lean_epilogue(std::integral_constant<int, ACT_MISH>{});
+                else
+                    lean_epilogue(std::integral_constant<int, ACT_NONE>{});
+                return;
+            }
+        }
+        generic_epilogue();
+    };
+
+    if constexpr (PERSIST) {
+        // ---- persistent staggered ring: the ring never drains between tiles.  Global stage g = (tile ordinal) * nk + kt lives in
+        //      slot g % NSTAGE; the DMA front runs D stages ahead and crosses into the next tile's operands, so a tile's first
+        //      K-steps are already in LDS when the previous tile's epilogue ends.  The two wave groups re-synchronise around
+        //      every epilogue (both store at the same time) and re-stagger afterwards.
+        constexpr int D = NSTAGE - 1;
+        const int G = gridDim.x;
+        const int my_tiles = (nblocks - (int)blockIdx.x + G - 1) / G;
+        const int total = my_tiles * nk;
+        int it_tile = blockIdx.x, it_k = 0, gi = 0, slot_i = 0;  // DMA front: tile, K-step inside it, global stage, ring slot
+        auto issue_next = [&]() {
+#pragma unroll
+            for (int pc = 0; pc < PPW; ++pc) issue_piece(slot_i, it_k, pc);
+            ++gi;
+            slot_i = slot_i + 1 == NSTAGE ? 0 : slot_i + 1;
+            if (++it_k == nk) {
+                it_k = 0;
+                it_tile += G;
+                if (it_tile < nblocks) {
+                    int sm, sn;
+                    tile_mn(it_tile, sm, sn);
+                    setup_src(sm, sn);
+                }
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (gi < total) issue_next();
+        wait_pieces(min(D - 1, total - 1));
+        __builtin_amdgcn_s_barrier();
+        const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+        int g = 0, slot_c = 0;
+        bf16x8 wf[NI], af[MI];
+        for (int t = 0; t < my_tiles; ++t) {
+            if (t > 0) {
+                tile_mn(blockIdx.x + t * G, m0, n0);
+                prep_epilogue();
+                zero_acc();
+            }
+            if (late) __builtin_amdgcn_s_barrier();
+            for (int kt = 0; kt < nk; ++kt) {
+                if (gi < total) issue_next();
+                read_frags(slot_c, wf, af);
+                // my pieces of global stage g+1 must have landed before the barrier that precedes anybody's next P phase
+                wait_pieces(g + 1 < total ? (gi - 1) - (g + 1) : 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_setprio(1);
+                mma(wf, af);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                ++g;
+                slot_c = slot_c + 1 == NSTAGE ? 0 : slot_c + 1;
+            }
+            if (!late) __builtin_amdgcn_s_barrier();  // same barrier count for both groups; both now store together
+            epilogue();
+        }
+        return;
+    }
+    constexpr bool HS = (VAR == 20 || VAR == 21);  // half-slab ring (21: timing-only, without the MFMAs)
+    constexpr int D = HS ? 3 : NSTAGE - 1;  // ring units issued ahead of the one being consumed
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < nk) issue(d);
+    if constexpr (HS)
+        wait_pieces(max(min(D - 1, nk - 1) - 1, 0));  // half-slabs 0 and 1 (K-step 0) have landed for this wave
+    else
+        wait_pieces(min(D - 1, nk - 1));  // K-step 0 has landed for this wave
+    __builtin_amdgcn_s_barrier();         // ... and for every wave
+
+    if constexpr (VAR == 0 || VAR == 14) {
+        // (VAR 14: timing-only, this schedule without the MFMAs)
+        // ---- plain ring: every wave does {refill, fragment reads, MFMAs} per K-step, one barrier per K-step
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + D < nk) issue(kt + D);  // refills slot (kt-1) % NSTAGE: its readers passed the previous barrier
+            bf16x8 wf[NI], af[MI];
+            read_frags(kt, wf, af);
+            if constexpr (VAR == 0) {
+                mma(wf, af);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(wf[i]));
+#pragma unroll
+                for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(af[j]));
+            }
+            if (kt + 1 < nk) {
+                wait_pieces(min(kt + D, nk - 1) - (kt + 1));
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+    } else {
+        // ---- ring + staggered wave groups (the two waves that share a SIMD never run the same phase together):
+        //   every wave alternates  P_k: {refill slot (k-1) % NSTAGE by DMA, ds_read the fragments of K-step k, counted vmcnt
+        //   for K-step k+1}  |barrier|  C_k: {32 MFMAs}  |barrier| ...; waves 4-7 run one barrier interval behind waves 0-3,
+        //   so in every interval one group feeds the matrix pipe while its SIMD partners do their LDS/DMA work.
+        // VAR >= 10: timing-only ablations (results are wrong by construction): 10 no DMA in the loop, 11 fragments read once, 12 no MFMA
+        const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+        if (late) __builtin_amdgcn_s_barrier();
+        bf16x8 wf[NI], af[MI];
+        for (int kt = 0; kt < nk; ++kt) {
+            // -- P_kt.  Slot (kt-1) % NSTAGE is free: both groups retired their reads of it (lgkmcnt(0) below) at least one barrier ago.
+            if constexpr (VAR == 3) {
+                if (kt + D < nk) {
+#pragma unroll
+                    for (int pc = 0; pc < PPW / 2; ++pc) issue_piece((kt + D) % NSTAGE, kt + D, pc);
+                }
+            } else {
+                if (VAR != 10 && kt + D < nk) issue(kt + D);
+            }
+            if (VAR != 11 || kt == 0) read_frags(kt, wf, af);
+            // my pieces of K-step kt+1 must have landed before the barrier that precedes anybody's P_{kt+1}
+            if constexpr (HS) {
+                // sub-step 2t+1 is followed by K-step t+1 = half-slabs kt+1 and kt+2; after an even sub-step nothing new is needed
+                if ((kt & 1) && kt + 1 < nk) wait_pieces(max(min(kt + D, nk - 1) - (kt + 2), 0));
+            } else {
+                wait_pieces(kt + 1 < nk ? min(kt + D, nk - 1) - (kt + 1) : 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // -- C_kt
+            __builtin_amdgcn_s_setprio(1);
+            if constexpr (VAR == 3) {
+                // second half of the DMA pieces rides in the MFMA phase (balances the two barrier intervals)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+#pragma unroll
+                    for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+                    if (i == NI / 2 - 1 && kt + D < nk) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int pc = PPW / 2; pc < PPW; ++pc) issue_piece((kt + D) % NSTAGE, kt + D, pc);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else if constexpr (VAR != 12 && VAR != 13 && VAR != 21) {
+                mma(wf, af);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(wf[i]));
+#pragma unroll
+                for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(af[j]));
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (!late) __builtin_amdgcn_s_barrier();  // same barrier count for both groups
+    }
+
+    epilogue();
 }
 
 int g_gemm_variant = 1;  // tuning knob (f5_tuning_set("gemm_variant", v)): 0 = plain ring, 1 = ring + staggered wave groups, 10-12 ablations
 int g_gemm_group = 8;    // tuning knob ("gemm_group"): token tiles per L2 patch (1 = feature-tile-fastest order)
+int g_gemm_persist_grid = 256;  // tuning knob ("gemm_persist_grid"): blocks of the persistent kernel (one per CU)
+int g_gemm_lean = 1;   // tuning knob ("gemm_lean"): 1 = lean epilogue on whole tiles, 0 = generic epilogue everywhere
+int g_gemm_nt = 0;     // tuning knob ("gemm_nt"): bit e = lean epilogue e (GemmEpi) uses non-temporal stores
 int g_gemm_stages = 5;   // tuning knob ("gemm_stages"): LDS ring slots of the 256x256 tile (4 = 128 KiB, 5 = 160 KiB = the whole LDS)
 
 template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmParams& p0, hipStream_t stream) {
     GemmParams p = p0;
     p.tile_group = g_gemm_group;
+    p.lean_epi = g_gemm_lean;
+    p.nt_store = (g_gemm_nt >> EPI) & 1;
     const int tiles_m = cdiv(p.M, 256), tiles_n = cdiv(p.N, BN);
     const int nblocks = tiles_m * tiles_n;
     dim3 grid(nblocks), block(512);
     if constexpr (BN == 256) {
         if (g_gemm_variant == 0)
             hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 0, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
-        else if (g_gemm_variant >= 10 && g_gemm_variant <= 14 && EPI == EPI_GATE_T) {
+        else if (g_gemm_variant >= 10 && g_gemm_variant <= 17 && EPI == EPI_GATE_T) {
             if (g_gemm_variant == 10) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 10, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
             if (g_gemm_variant == 11) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 11, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
             if (g_gemm_variant == 12) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 12, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
             if (g_gemm_variant == 13) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 13, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
             if (g_gemm_variant == 14) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 14, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
+            if (g_gemm_variant == 15) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 15, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
+            if (g_gemm_variant == 16) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 16, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
+            if (g_gemm_variant == 17) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 17, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
         } else if (g_gemm_variant == 20 && MODE == GEMM_DENSE && p.K % 64 == 0)
             hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI, 20, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
         else if (g_gemm_variant == 21 && MODE == GEMM_DENSE && EPI == EPI_GATE_T && p.K % 64 == 0)
             hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI_GATE_T, 21, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
         else if (g_gemm_variant == 3)
             hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 3, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
+        else if ((g_gemm_variant == 31 || g_gemm_variant == 32) && MODE == GEMM_DENSE && EPI == EPI_GATE_T) {
+            const dim3 pg(nblocks < g_gemm_persist_grid ? nblocks : g_gemm_persist_grid);
+            if (g_gemm_variant == 31) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI_GATE_T, 31, 5>), pg, block, 0, stream, p, tiles_n, nblocks);
+            if (g_gemm_variant == 32) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI_GATE_T, 32, 5>), pg, block, 0, stream, p, tiles_n, nblocks);
+        } else if (g_gemm_variant == 30 && MODE == GEMM_DENSE)
+            hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI, 30, 5>), dim3(nblocks < g_gemm_persist_grid ? nblocks : g_gemm_persist_grid), block, 0, stream, p, tiles_n, nblocks);
         else if (g_gemm_stages == 5)
             hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 1, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
         else

@@ -45,6 +45,7 @@ int launch_cfg_step(const float* x_base, const float* vc, const float* vu, int l
 int launch_final_where(const float* cond, const float* x, const int32_t* lens, int B, int N, int mel, float* out, hipStream_t stream);
 // mask[b][n] = n < durations[b]
 int launch_len_mask(const int32_t* durations, int B, int N, uint8_t* mask, hipStream_t stream);
+int launch_rowbits(const uint8_t* mask, int rows, uint8_t* bits, hipStream_t stream);
 int launch_fill_f32(float* dst, size_t n, float v, hipStream_t stream);
 // dst[0..n) = host_vals[0..n), passed through kernel arguments (no async-memcpy from pageable host memory)
 int launch_set_floats(float* dst, const float* host_vals, int n, hipStream_t stream);

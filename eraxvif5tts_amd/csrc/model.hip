@@ -65,7 +65,8 @@ struct f5_plan_s {
     float *tvals = nullptr, *coefs = nullptr, *te[2] = {nullptr, nullptr}, *grn_scratch = nullptr, *traj = nullptr, *xmid = nullptr;
     float *cond_in = nullptr, *rope = nullptr, *tap_scratch = nullptr;
     void *hT = nullptr, *cT = nullptr, *yT = nullptr, *qkv = nullptr, *ffh = nullptr, *abase = nullptr, *xin = nullptr, *teT = nullptr, *te_h = nullptr;
-    uint8_t *filler = nullptr, *mask = nullptr;
+    uint8_t *filler = nullptr, *mask = nullptr, *rowbits = nullptr;
+    const uint8_t* rowbits_src = nullptr;  // the row mask `rowbits` was built from (GemmParams::rowbits)
     int32_t *text_in = nullptr, *lens_in = nullptr, *dur_in = nullptr;
     int rope_n = 0;
     int gemm_kernel = -1, attn_kernel = -1;  // -1 = auto (tuned kernel when it supports the problem)
@@ -364,6 +365,7 @@ extern "C" int f5_plan_create(f5_model_t m, int max_batch, int max_seq, int max_
         if ((rc = A.alloc_t(&p->grn_scratch, (size_t)max_batch * 2 * td + max_batch))) break;
         if ((rc = A.alloc_t(&p->filler, bn))) break;
         if ((rc = A.alloc_t(&p->mask, 2 * bn))) break;
+        if ((rc = A.alloc_t(&p->rowbits, (size_t)(2 * bn / 128 + 1) * 16))) break;
         if ((rc = A.alloc_t(&p->traj, (size_t)(max_evals + 1) * bn * mel))) break;
         if ((rc = A.alloc_t(&p->xmid, bn * mel))) break;
         if ((rc = A.alloc_t(&p->cond_in, bn * mel))) break;
@@ -605,6 +607,7 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         g.A = p->cT; g.lda = inner; g.W = b.w_o; g.ldw = inner; g.M = rows; g.N = D; g.K = inner;
         g.bias = b.b_o; g.out_t = p->yT; g.ldo = D; g.gate = ml + 2 * D; g.gate_bstride = mod_bstride; g.rows_per_batch = N;
         g.rowmask = mask;
+        g.rowbits = (mask && mask == p->rowbits_src) ? p->rowbits : nullptr;
         F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_GATE_T, st));
         // x += y; n2 = LN(x) * (1 + scale_mlp) + shift_mlp
         F5_TRY(launch_layernorm_add(P, p->xres, D, rows, D, p->yT, D, ml + 4 * D, ml + 3 * D, mod_bstride, N, 1, p->hT, D, st));
@@ -680,6 +683,8 @@ static int sample_body(f5_plan_s* p, const SampleArgs& a, hipStream_t st) {
         F5_TRY(launch_len_mask(p->dur_in, B, N, p->mask, st));
         if (a.cfg_on) F5_HIP(hipMemcpyAsync(p->mask + bn, p->mask, bn, hipMemcpyDeviceToDevice, st));
         mask = p->mask;
+        F5_TRY(launch_rowbits(mask, (a.cfg_on ? 2 : 1) * (int)bn, p->rowbits, st));
+        p->rowbits_src = mask;
     }
     const int nb = a.cfg_on ? 2 * B : B;
     for (int s = 0; s < a.steps; ++s) {

@@ -228,7 +228,7 @@ extern "C" int f5_bench_attention(int kernel, int B, int N, int H, int iters, fl
     return sync_and_release(a, st, rc);
 }
 
-extern int g_gemm_variant, g_gemm_stages, g_gemm_group, g_attn_ablate, g_attn_variant;
+extern int g_gemm_variant, g_gemm_stages, g_gemm_group, g_gemm_persist_grid, g_gemm_lean, g_gemm_nt, g_attn_ablate, g_attn_variant;
 extern "C" int f5_tuning_set(const char* key, int value) {
     if (!key) return f5_fail(F5_EINVAL, "null key");
     if (strcmp(key, "gemm_variant") == 0) {
@@ -245,6 +245,19 @@ extern "C" int f5_tuning_set(const char* key, int value) {
     }
     if (strcmp(key, "gemm_group") == 0) {
         g_gemm_group = value;
+        return 0;
+    }
+    if (strcmp(key, "gemm_nt") == 0) {
+        g_gemm_nt = value;
+        return 0;
+    }
+    if (strcmp(key, "gemm_lean") == 0) {
+        g_gemm_lean = value != 0;
+        return 0;
+    }
+    if (strcmp(key, "gemm_persist_grid") == 0) {
+        if (value < 8 || value > 4096) return f5_fail(F5_EINVAL, "gemm_persist_grid must be in [8, 4096]");
+        g_gemm_persist_grid = value;
         return 0;
     }
     if (strcmp(key, "gemm_stages") == 0) {

@@ -10,6 +10,9 @@ lib = _lib.load()
 rows, seq = 65536, 1024
 sites = {0: ("qkv  N3072 K1024", 2.0 * rows * 3072 * 1024), 1: ("ff1  N2048 K1024", 2.0 * rows * 2048 * 1024),
          2: ("ff2  N1024 K2048", 2.0 * rows * 1024 * 2048), 3: ("outp N1024 K1024", 2.0 * rows * 1024 * 1024)}
+import os
+if os.environ.get("LEAN") is not None:
+    _lib.check(lib.f5_tuning_set(b"gemm_lean", int(os.environ["LEAN"])))
 variants = [int(v) for v in (sys.argv[1:] or ["0", "1"])]
 res = {}
 for rnd in range(3):
