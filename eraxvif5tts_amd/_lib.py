@@ -48,6 +48,7 @@ _PROTOS = {
     "f5_plan_set_tap": (_I, [_P, C.c_char_p, _P]),
     "f5_plan_set_option": (_I, [_P, C.c_char_p, _I]),
     "f5_op_linear": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
+    "f5_op_linear_fused": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P]),
     "f5_op_layernorm_modulate": (_I, [_I, _I, _P, _P, _P, _P, _P]),
     "f5_op_attention": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "f5_op_conv_pos_embed": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),

@@ -13,54 +13,9 @@
 //   * GEMM_CONV31: the same engine as an implicit GEMM for the grouped Conv1d(k=31): K-steps walk (tap, 64 channels),
 //     the DMA source row is shifted by tap-15 and rows outside the utterance read a zero page.
 //   * rows >= M / features >= N are clamped on load and dropped in the epilogue, so no padding contract on the caller.
-#include "gemm.h"
-#include <type_traits>
+#include "gemm_tile.h"
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];  // zero-initialised
-
-// compile-time loop: keeps accumulator indices static even when the optimizer refuses a "#pragma unroll"
-// (a runtime-indexed accumulator array would be demoted to scratch memory)
-template <int N, int I = 0, typename F> __device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<N, I + 1>(f);
-    }
-}
-
-// exp2/rcp forms of the activations for the bf16 epilogues (the output rounding to bf16 dominates their ~1 ulp error):
-//   gelu_tanh(x) = 0.5 x (1 + tanh(u)) = x * sigmoid(2u),  u = sqrt(2/pi) (x + 0.044715 x^3)
-//   mish(x)      = x tanh(softplus(x)) = x * n / (n + 2),  n = e^x (e^x + 2)
-__device__ __forceinline__ float fast_gelu_tanh(float x) {
-    const float a = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
-    const float u2 = x * (a + (a * 0.044715f) * (x * x));
-    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u2));
-}
-__device__ __forceinline__ float fast_mish(float x) {
-    const float w = __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
-    const float n = w * (w + 2.0f);
-    return x > 20.0f ? x : x * n * __builtin_amdgcn_rcpf(n + 2.0f);
-}
-typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-// Two adjacent 16-feature tiles of one token tile: lane (row r = lane>>4) holds features 4r..4r+3 of tile A and of tile B.
-// v_permlane16_swap exchanges the odd 16-lane rows of A with the even rows of B, after which every lane owns 8 consecutive
-// features (rows 0/2: tile A features 8*(r>>1).., rows 1/3: tile B) -> one 16-byte store instead of two 8-byte ones
-// (the epilogue is store-issue bound).
-__device__ __forceinline__ u32x4 pair_swap(bf16x4 a, bf16x4 b) {
-    const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
-    const u32x2 s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
-    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
-    return u32x4{s0[0], s1[0], s0[1], s1[1]};
-}
-__device__ __forceinline__ bf16x4 to_bf16x4(const f32x4& v) { return bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]}; }
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-__device__ __forceinline__ void dma16(const void* src, char* lds_wave_base) {
-    // wave-uniform LDS base + lane*16 <- 16 bytes from each lane's own global address
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
-}
 
 template <int BN, int WM, int MODE, int EPI, int VAR, int NS>
 __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(GemmParams p, int tiles_n, int nblocks) {
@@ -198,6 +153,16 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
     auto issue = [&](int kt) {
 #pragma unroll
         for (int pc = 0; pc < PPW; ++pc) issue_piece(kt % NSTAGE, kt, pc);
+    };
+    // VAR 2: K-steps are fetched in (even, odd) pairs, piece by piece.  The two 64-byte halves of every 128-byte line are then
+    // requested by ADJACENT instructions, which the vector L1 merges into one line fetch (tools/dma_probe.hip: 0.39 us per K-step
+    // of operand feed instead of 0.58 us; with 64 cycles between the halves the gain is gone).
+    [[maybe_unused]] auto issue_pair = [&](int kt) {
+#pragma unroll
+        for (int pc = 0; pc < PPW; ++pc) {
+            issue_piece(kt % NSTAGE, kt, pc);
+            issue_piece((kt + 1) % NSTAGE, kt + 1, pc);
+        }
     };
 
     // ---- fragment read offsets (bytes inside a stage)
@@ -572,10 +537,17 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
     }
     constexpr bool HS = (VAR == 20 || VAR == 21);  // half-slab ring (21: timing-only, without the MFMAs)
     constexpr int D = HS ? 3 : NSTAGE - 1;  // ring units issued ahead of the one being consumed
+    if constexpr (VAR == 2) {  // nk even and >= 4 (launcher)
+        issue_pair(0);
+        issue_pair(2);
+    } else {
 #pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (d < nk) issue(d);
-    if constexpr (HS)
+        for (int d = 0; d < D; ++d)
+            if (d < nk) issue(d);
+    }
+    if constexpr (VAR == 2)
+        wait_pieces(2);  // pair (2, 3) may be in flight (and, harmlessly waited for, the last piece of K-step 1)
+    else if constexpr (HS)
         wait_pieces(max(min(D - 1, nk - 1) - 1, 0));  // half-slabs 0 and 1 (K-step 0) have landed for this wave
     else
         wait_pieces(min(D - 1, nk - 1));  // K-step 0 has landed for this wave
@@ -617,6 +589,9 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
 #pragma unroll
                     for (int pc = 0; pc < PPW / 2; ++pc) issue_piece((kt + D) % NSTAGE, kt + D, pc);
                 }
+            } else if constexpr (VAR == 2) {
+                // odd K-step: pair (kt+3, kt+4) into the slots of K-steps kt-2 and kt-1
+                if ((kt & 1) && kt + 4 < nk) issue_pair(kt + 3);
             } else {
                 if (VAR != 10 && kt + D < nk) issue(kt + D);
             }
@@ -625,6 +600,10 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
             if constexpr (HS) {
                 // sub-step 2t+1 is followed by K-step t+1 = half-slabs kt+1 and kt+2; after an even sub-step nothing new is needed
                 if ((kt & 1) && kt + 1 < nk) wait_pieces(max(min(kt + D, nk - 1) - (kt + 2), 0));
+            } else if constexpr (VAR == 2) {
+                // whole pairs issued behind the pair that holds K-step kt+1 may stay in flight
+                const int last = min((kt & 1) ? kt + 4 : kt + 3, nk - 1);
+                wait_pieces(kt + 1 < nk ? ((last - ((kt + 1) | 1)) / 2) * 2 : 0);
             } else {
                 wait_pieces(kt + 1 < nk ? min(kt + D, nk - 1) - (kt + 1) : 0);
             }
@@ -697,6 +676,8 @@ template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmPa
             hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI_GATE_T, 21, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
         else if (g_gemm_variant == 3)
             hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 3, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
+        else if (g_gemm_variant == 2 && MODE == GEMM_DENSE && p.K % 64 == 0 && p.K >= 128)
+            hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI, 2, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
         else if ((g_gemm_variant == 31 || g_gemm_variant == 32) && MODE == GEMM_DENSE && EPI == EPI_GATE_T) {
             const dim3 pg(nblocks < g_gemm_persist_grid ? nblocks : g_gemm_persist_grid);
             if (g_gemm_variant == 31) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI_GATE_T, 31, 5>), pg, block, 0, stream, p, tiles_n, nblocks);
@@ -733,6 +714,7 @@ bool gemm_fast_supported(const GemmParams& p, int precision, int mode, int epi) 
 }
 
 int launch_gemm_fast(const GemmParams& p, int mode, int epi, hipStream_t stream) {
+    if (g_gemm_variant == 1 && gemm_big_supported(p, mode, epi)) return launch_gemm_big(p, epi, stream);
     if (mode == GEMM_CONV31) {
         if (epi == EPI_STORE_T) return launch_fast<64, 32, GEMM_CONV31, EPI_STORE_T>(p, stream);
         if (epi == EPI_GATE_T) return launch_fast<64, 32, GEMM_CONV31, EPI_GATE_T>(p, stream);

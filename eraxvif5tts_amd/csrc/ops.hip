@@ -38,6 +38,49 @@ extern "C" int f5_op_linear(int precision, int kernel, int M, int N, int K, cons
     return sync_and_release(a, st, rc);
 }
 
+// One DiT block linear with its fused store epilogue, as the sampler launches it (test hook; bf16 output converted back to fp32):
+//   epi 0 (EPI_STORE_T): out = act(A W^T + b)                         FF1 (modules.py:258-264)
+//   epi 5 (EPI_GATE_T):  out = gate[n] * act(A W^T + b), 0 where rowmask[m] == 0   attention out / FF2 with the AdaLN gate (modules.py:499-501,635,639)
+//   epi 4 (EPI_ROPE_T):  out = rope(A W^T + b) on the q/k columns of the first rope_heads heads (N = 3 * inner, modules.py:452-461)
+extern "C" int f5_op_linear_fused(int kernel, int epi, int M, int N, int K, const float* A, const float* W, const float* bias, int act,
+                                  const float* gate, const uint8_t* rowmask, const float* rope, int rope_heads, int seq, float* out,
+                                  f5_stream_t stream) {
+    F5_TRY(f5_check_device());
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !out) return f5_fail(F5_EINVAL, "bad argument");
+    if (!(epi == EPI_STORE_T || epi == EPI_GATE_T || epi == EPI_ROPE_T)) return f5_fail(F5_EINVAL, "f5_op_linear_fused: epilogue %d", epi);
+    if (epi == EPI_ROPE_T && (!rope || seq <= 0 || M % seq != 0 || N % 3 != 0 || (N / 3) % 64 != 0)) return f5_fail(F5_EINVAL, "bad RoPE arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int Kp = (int)round_up(K, 64), Mp = (int)round_up(M, 256), Np = (int)round_up(N, 256);
+    DevArena a;
+    void *At = nullptr, *Wt = nullptr, *Ot = nullptr;
+    uint8_t* bits = nullptr;
+    int rc = 0;
+    do {
+        if ((rc = a.alloc(&At, (size_t)Mp * Kp * 2))) break;
+        if ((rc = a.alloc(&Wt, (size_t)Np * Kp * 2))) break;
+        if ((rc = a.alloc(&Ot, (size_t)Mp * N * 2))) break;
+        if ((rc = a.alloc_t(&bits, (size_t)(Mp / 128 + 1) * 16))) break;
+        if ((rc = launch_convert_pad(F5_PREC_BF16, A, K, M, K, Kp, At, Kp, st))) break;
+        if ((rc = launch_convert_pad(F5_PREC_BF16, W, K, N, K, Kp, Wt, Kp, st))) break;
+        GemmParams g;
+        memset(&g, 0, sizeof(g));
+        g.A = At; g.lda = Kp; g.W = Wt; g.ldw = Kp; g.M = M; g.N = N; g.K = Kp;
+        g.bias = bias; g.act = act; g.out_t = Ot; g.ldo = N; g.rows_per_batch = seq > 0 ? seq : M;
+        if (epi == EPI_GATE_T) {
+            g.gate = gate;
+            g.rowmask = rowmask;
+            if (rowmask) {
+                if ((rc = launch_rowbits(rowmask, M, bits, st))) break;
+                g.rowbits = bits;
+            }
+        }
+        if (epi == EPI_ROPE_T) { g.rope = rope; g.rope_inner = N / 3; g.rope_heads = rope_heads; }
+        if ((rc = launch_gemm(g, F5_PREC_BF16, GEMM_DENSE, epi, kernel, st))) break;
+        rc = launch_convert_back(F5_PREC_BF16, Ot, N, M, N, out, N, st);
+    } while (0);
+    return sync_and_release(a, st, rc);
+}
+
 extern "C" int f5_op_layernorm_modulate(int rows, int dim, const float* x, const float* scale, const float* shift, float* out,
                                         f5_stream_t stream) {
     F5_TRY(f5_check_device());
@@ -228,7 +271,7 @@ extern "C" int f5_bench_attention(int kernel, int B, int N, int H, int iters, fl
     return sync_and_release(a, st, rc);
 }
 
-extern int g_gemm_variant, g_gemm_stages, g_gemm_group, g_gemm_persist_grid, g_gemm_lean, g_gemm_nt, g_attn_ablate, g_attn_variant;
+extern int g_gemm_variant, g_gemm_stages, g_gemm_group, g_gemm_persist_grid, g_gemm_lean, g_gemm_nt, g_gemm_big, g_gemm_big_ablate, g_attn_ablate, g_attn_variant;
 extern "C" int f5_tuning_set(const char* key, int value) {
     if (!key) return f5_fail(F5_EINVAL, "null key");
     if (strcmp(key, "gemm_variant") == 0) {
@@ -245,6 +288,14 @@ extern "C" int f5_tuning_set(const char* key, int value) {
     }
     if (strcmp(key, "gemm_group") == 0) {
         g_gemm_group = value;
+        return 0;
+    }
+    if (strcmp(key, "gemm_big_ablate") == 0) {
+        g_gemm_big_ablate = value;
+        return 0;
+    }
+    if (strcmp(key, "gemm_big") == 0) {
+        g_gemm_big = value;
         return 0;
     }
     if (strcmp(key, "gemm_nt") == 0) {

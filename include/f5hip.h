@@ -137,6 +137,16 @@ int f5_plan_set_option(f5_plan_t p, const char* key, int value);
  * kernel: 0 = reference tile kernel, 1 = tuned 256x256 LDS-DMA kernel (bf16 only; shapes must be tile multiples). */
 int f5_op_linear(int precision, int kernel, int M, int N, int K, const float* A, const float* W, const float* bias, int act,
                  float* out, f5_stream_t stream);
+/* One DiT block linear with the fused store epilogue the sampler uses for it (bf16 path; output converted back to f32):
+ *   epi 0: out = act(A W^T + b)                                      FeedForward first linear, reference model/modules.py:258-264
+ *   epi 5: out = gate[n] * act(A W^T + b), rows with rowmask[m]==0 -> 0  attention to_out / FF second linear times the AdaLN gate,
+ *                                                                    modules.py:499-501,635,639 (gate f32 [N] or NULL, rowmask u8 [M] or NULL)
+ *   epi 4: out = rope(A W^T + b): fused QKV projection (N = 3*inner), x_transformers rotary on adjacent pairs of the q and k columns
+ *          of the first rope_heads heads, modules.py:452-461; rope f32 [seq][32][2] (cos, sin), token position = m % seq
+ * kernel: 0 = reference tile kernel, 1 = tuned kernels.  All pointers are device pointers. */
+int f5_op_linear_fused(int kernel, int epi, int M, int N, int K, const float* A, const float* W, const float* bias, int act,
+                       const float* gate, const uint8_t* rowmask, const float* rope, int rope_heads, int seq, float* out,
+                       f5_stream_t stream);
 /* LayerNorm(eps 1e-6, no affine) * (1 + scale) + shift ; x f32 [rows, dim]; scale/shift f32 [dim] */
 int f5_op_layernorm_modulate(int rows, int dim, const float* x, const float* scale, const float* shift, float* out,
                              f5_stream_t stream);

@@ -57,6 +57,69 @@ def _attn_ref(qkv, mask):
 
 
 @pytest.mark.parametrize("prec", [P_FP32, P_BF16])
+def _fused_ref(epi, A, W, b, act, gate, rowmask, rope, rope_heads, seq):
+    """fp64 restatement of the three fused store epilogues (oracle/cpu_ref.py: dit_block's linears, apply_rope)."""
+    import gpu_helpers as G
+    v = A.double() @ W.double().t() + b.double()
+    if act == "gelu_tanh":
+        v = F.gelu(v, approximate="tanh")
+    if epi == G.EPI_GATE_T:
+        if gate is not None:
+            v = v * gate.double()
+        if rowmask is not None:
+            v = v * rowmask.double()[:, None]
+    if epi == G.EPI_ROPE_T:
+        M, N = v.shape
+        inner = N // 3
+        pos = torch.arange(M) % seq
+        cs = rope.double()[pos]  # [M, 32, 2]
+        cos, sin = cs[..., 0], cs[..., 1]
+        v = v.clone()
+        for part in range(2):  # q, k
+            for h in range(rope_heads):
+                c0 = part * inner + h * 64
+                x = v[:, c0:c0 + 64].reshape(M, 32, 2)
+                x0, x1 = x[..., 0], x[..., 1]
+                v[:, c0:c0 + 64] = torch.stack([x0 * cos - x1 * sin, x1 * cos + x0 * sin], dim=-1).reshape(M, 64)
+    return v.float()
+
+
+# whole-tile shapes (lean epilogue), ragged rows / narrow tiles (generic epilogue), >= 160 tiles (where the 4-wave kernel applies)
+@pytest.mark.parametrize("knobs", [{}, {"gemm_lean": 0}, {"gemm_big": 1}], ids=["default", "generic_epilogue", "four_wave_kernel"])
+@pytest.mark.parametrize("epi_name,shape,seq", [("store", (512, 1024, 256), 0), ("store", (10240, 1024, 128), 0), ("store", (10300, 2048, 192), 0),
+                                                ("gate", (768, 512, 128), 0), ("gate", (10240, 1024, 256), 0), ("gate", (10301, 1024, 128), 0),
+                                                ("rope", (1024, 768, 128), 256), ("rope", (4096, 3072, 128), 1024), ("rope", (4120, 3072, 128), 1030)])
+def test_linear_fused_epilogues(knobs, epi_name, shape, seq):
+    import gpu_helpers as G
+    from eraxvif5tts_amd import _lib
+    lib = _lib.load()
+    M, N, K = shape
+    epi = {"store": G.EPI_STORE_T, "gate": G.EPI_GATE_T, "rope": G.EPI_ROPE_T}[epi_name]
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    A, W, b = G.bf16_round(torch.randn(M, K, generator=g)), G.bf16_round(torch.randn(N, K, generator=g) / math.sqrt(K)), torch.randn(N, generator=g)
+    act = "gelu_tanh" if epi_name == "store" else "none"
+    gate = torch.randn(N, generator=g) if epi_name == "gate" else None
+    rowmask = (torch.rand(M, generator=g) > 0.2) if epi_name == "gate" else None
+    rope, heads = None, 0
+    if epi_name == "rope":
+        ang = torch.rand(seq, 32, generator=g) * 6.28
+        rope, heads = torch.stack([ang.cos(), ang.sin()], dim=-1), (1 if N == 3072 else N // 3 // 64)
+    ref = _fused_ref(epi, A, W, b, act, gate, rowmask, rope, heads, seq)
+    try:
+        for k, v in knobs.items():
+            _lib.check(lib.f5_tuning_set(k.encode(), v))
+        out = G.op_linear_fused(1, epi, A, W, b, act, gate, rowmask, rope, heads, seq)
+    finally:
+        for k in knobs:
+            _lib.check(lib.f5_tuning_set(k.encode(), {"gemm_lean": 1, "gemm_big": 0}[k]))
+    base = G.op_linear_fused(0, epi, A, W, b, act, gate, rowmask, rope, heads, seq)
+    assert rel_l2(base, ref) < 3e-3   # bf16 output rounding: 2^-9 relative per element
+    assert rel_l2(out, ref) < 3e-3
+    assert rel_l2(out, base) < 1e-3   # same contraction up to fp32 summation order and the exp2/rcp form of GELU
+    if rowmask is not None:
+        assert torch.count_nonzero(out[~rowmask]) == 0  # masked rows are exact zeros (modules.py:499-501)
+
+
 @pytest.mark.parametrize("B,N,H,masked", [(2, 56, 2, True), (1, 41, 2, False), (2, 200, 3, True), (1, 64, 16, False)])
 def test_attention_reference_kernel(prec, B, N, H, masked):
     import gpu_helpers as G

@@ -8,9 +8,12 @@ import gpu_helpers as G
 _lib.require_gpu()
 lib = _lib.load()
 bad = 0
+import os
+if os.environ.get("BIG") is not None:
+    _lib.check(lib.f5_tuning_set(b"gemm_big", int(os.environ["BIG"])))
 for v in [int(x) for x in sys.argv[1:]]:
     _lib.check(lib.f5_tuning_set(b"gemm_variant", v))
-    for (M, N, K) in [(256, 256, 32), (512, 1024, 1024), (300, 3072, 128), (2048, 2048, 2048), (1000, 256, 96), (16384, 3072, 256), (16640, 2048, 64), (40960, 1024, 32)]:
+    for (M, N, K) in [(256, 256, 32), (512, 1024, 1024), (300, 3072, 128), (2048, 2048, 2048), (1000, 256, 96), (16384, 3072, 256), (16640, 2048, 64), (40960, 1024, 32), (40960, 1024, 1024), (41000, 2048, 96), (65536, 256, 64)]:
         g = torch.Generator().manual_seed(M + N + K)
         A, W, b = G.bf16_round(torch.randn(M, K, generator=g)), G.bf16_round(torch.randn(N, K, generator=g) / math.sqrt(K)), torch.randn(N, generator=g)
         ref = (A.double() @ W.double().t() + b.double()).float()

@@ -13,6 +13,8 @@ sites = {0: ("qkv  N3072 K1024", 2.0 * rows * 3072 * 1024), 1: ("ff1  N2048 K102
 import os
 if os.environ.get("LEAN") is not None:
     _lib.check(lib.f5_tuning_set(b"gemm_lean", int(os.environ["LEAN"])))
+if os.environ.get("BIG") is not None:
+    _lib.check(lib.f5_tuning_set(b"gemm_big", int(os.environ["BIG"])))
 variants = [int(v) for v in (sys.argv[1:] or ["0", "1"])]
 res = {}
 for rnd in range(3):

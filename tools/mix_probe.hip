@@ -1,0 +1,155 @@
+// mix_probe.hip -- how do MFMA issue, LDS-DMA issue and LDS fragment reads overlap inside one instruction stream on gfx950?
+// Standalone: every workgroup runs nk "K-steps" of a 256x256x32 tile worth of work (64 MFMAs per wave with 4 waves, 32 with 8),
+// optionally with the operand feed (8 / 4 DMA pieces per wave per step, pair halves adjacent), the fragment reads (16 / 12 per
+// wave per step) and the per-step barrier.   hipcc --offload-arch=gfx950 -O3 tools/mix_probe.hip -o tools/bin/mix_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+__device__ __forceinline__ void dma16(const void* src, char* lds) { __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds, 16, 0, 0); }
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void mfma_acc(f32x4& c, const bf16x8& w, const bf16x8& a) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(w), "v"(a));
+}
+template <int OFF> __device__ __forceinline__ void lds_read16(bf16x8& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N, int I = 0, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<N, I + 1>(f); }
+}
+
+// 4 waves: per step per wave 64 MFMA, 8 DMA (as 4 adjacent pairs... 16 per two steps), 16 ds_read
+template <bool MFMA, bool DMA, bool RD, bool BAR, int RDPOS, int DMAMODE = 0>
+__global__ __launch_bounds__(256, 1) void mix4(const char* A, const char* W, int ld_b, int nk, float* sink) {
+    __shared__ __attribute__((aligned(16))) char smem[5 * 32768];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bid = blockIdx.x, swz = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int tile_m = swz >> 2, tile_n = swz & 3;
+    const char* a_src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a_src[j] = A + (size_t)(tile_m * 256 + wave * 64 + j * 16 + (lane >> 2)) * ld_b + (lane & 3) * 16;
+    const char* w_src = W + (size_t)(tile_n * 256 + wave * 64 + (lane >> 2)) * ld_b + (lane & 3) * 16;
+    const size_t w_step = (size_t)16 * ld_b;
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 fw[2][8], fa[2][8];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { fw[b][i] = bf16x8{}; fa[b][i] = bf16x8{}; }
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem + (lane & 15) * 64 + (lane >> 4) * 16;
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+    // buffer resources over A and W (raw, no swizzle): base, stride 0, num_records = 2^31, flags (DATA_FORMAT=32 etc. for gfx9 raw buffer)
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, (short)0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)W, (short)0, 0x7fffffff, 0x00020000);
+    unsigned a_off32[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a_off32[j] = (unsigned)(a_src[j] - A);
+    const unsigned w_off32 = (unsigned)(w_src - W);
+    auto pair_piece = [&](int kt, int pc) {   // pieces pc of K-steps kt and kt+1, adjacent
+        char* s0 = smem + (kt % 5) * 32768 + wave * 4096;
+        char* s1 = smem + ((kt + 1) % 5) * 32768 + wave * 4096;
+        const size_t ko = (size_t)kt * 64;
+        const int off = pc < 4 ? pc * 1024 : 16384 + (pc - 4) * 1024;
+        if constexpr (DMAMODE == 2) {
+            const unsigned vo = pc < 4 ? a_off32[pc] : w_off32 + (unsigned)((pc - 4) * w_step);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(pc < 4 ? rsrc_a : rsrc_w, (lptr_t)(s0 + off), 16, vo, (int)ko, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(pc < 4 ? rsrc_a : rsrc_w, (lptr_t)(s1 + off), 16, vo, (int)ko, 64, 0);
+        } else {
+            const char* s = pc < 4 ? a_src[pc] : w_src + (pc - 4) * w_step;
+            dma16(s + ko, s0 + off);
+            dma16(s + ko + 64, s1 + off);
+        }
+    };
+    if (DMA) {
+        for (int pc = 0; pc < 8; ++pc) pair_piece(0, pc);
+        for (int pc = 0; pc < 8; ++pc) pair_piece(2, pc);
+    }
+    auto step = [&](int kt, auto curc, auto issuec) {
+        constexpr int CUR = decltype(curc)::value;
+        constexpr bool ISSUE = decltype(issuec)::value;
+        if (DMA) wait_vm<16>();
+        if (BAR) __builtin_amdgcn_s_barrier();
+        if constexpr (DMA && ISSUE && DMAMODE == 1) {
+#pragma unroll
+            for (int pc = 0; pc < 8; ++pc) pair_piece(kt + 4, pc);
+        }
+        const unsigned rb = lds0 + ((kt + 1) % 5) * 32768;
+        static_for<64>([&](auto tc) {
+            constexpr int t = decltype(tc)::value, i = t / 8, j = t % 8;
+            if constexpr (MFMA) mfma_acc(acc[i][j], fw[CUR][i], fa[CUR][j]);
+            if constexpr (DMA && ISSUE && DMAMODE != 1 && t < 32 && (t & 3) == 3) pair_piece(kt + 4, t / 4);
+            if constexpr (RD) {
+                constexpr int t0 = RDPOS == 0 ? 32 : 0;     // reads woven into the second / first half of the MFMAs
+                if constexpr (RDPOS < 2 && t >= t0 && t < t0 + 32 && (t & 1) == 1) {
+                    constexpr int rd = (t - t0) / 2;
+                    if constexpr (rd < 8) lds_read16<rd * 1024>(fw[CUR ^ 1][rd], rb + 16384);
+                    else lds_read16<(rd - 8) * 1024>(fa[CUR ^ 1][rd - 8], rb);
+                }
+                if constexpr (RDPOS == 2 && t < 16) {       // burst at the top
+                    if constexpr (t < 8) lds_read16<t * 1024>(fw[CUR ^ 1][t], rb + 16384);
+                    else lds_read16<(t - 8) * 1024>(fa[CUR ^ 1][t - 8], rb);
+                }
+            }
+        });
+        if (RD) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, std::integral_constant<int, 0>{}, std::true_type{});
+        step(kt + 1, std::integral_constant<int, 1>{}, std::false_type{});
+    }
+    wait_vm<0>();
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += acc[i][j][0];
+    if (sink && s == 12345.f) sink[0] = s;
+}
+
+template <bool MFMA, bool DMA, bool RD, bool BAR, int RDPOS, int DMAMODE = 0> void run(const char* name, const char* A, const char* W, float* sink) {
+    const int K = 1024, nk = K / 32, blocks = 1024;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((mix4<MFMA, DMA, RD, BAR, RDPOS, DMAMODE>), dim3(blocks), dim3(256), 0, 0, A, W, K * 2, nk, sink);
+    hipEventRecord(e0);
+    const int reps = 10;
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((mix4<MFMA, DMA, RD, BAR, RDPOS, DMAMODE>), dim3(blocks), dim3(256), 0, 0, A, W, K * 2, nk, sink);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double us = ms * 1e3 / reps, per_step = us / 4.0 / nk;
+    printf("%-64s %8.1f us  %6.3f us/K-step  %7.1f TFLOP/s-equiv\n", name, us, per_step, 2.0 * 65536 * 1024 * 1024 / us * 1e-6);
+    fflush(stdout);
+}
+
+int main() {
+    const size_t M = 65536, N = 1024, K = 1024;
+    char *A, *W; float* sink;
+    hipMalloc(&A, M * K * 2 + (1 << 20)); hipMalloc(&W, N * K * 2 + (1 << 20)); hipMalloc(&sink, 64);
+    hipMemset(A, 0, M * K * 2); hipMemset(W, 0, N * K * 2);
+    run<true, false, false, false, 0>("MFMA only", A, W, sink);
+    run<true, false, false, true, 0>("MFMA + barrier", A, W, sink);
+    run<false, true, false, true, 0>("DMA (pairs adjacent) + barrier", A, W, sink);
+    run<true, true, false, false, 0>("MFMA + DMA", A, W, sink);
+    run<true, true, false, true, 0>("MFMA + DMA + barrier", A, W, sink);
+    run<true, true, false, false, 0, 1>("MFMA + DMA burst at top of even steps", A, W, sink);
+    run<true, true, false, false, 0, 2>("MFMA + DMA woven, raw_buffer_load_lds", A, W, sink);
+    run<false, true, false, true, 0, 2>("DMA only, raw_buffer_load_lds + barrier", A, W, sink);
+    run<true, true, true, true, 1, 2>("MFMA + DMA(buffer) + ds_read (1st half) + barrier", A, W, sink);
+    run<true, false, true, false, 0>("MFMA + ds_read (2nd half)", A, W, sink);
+    run<true, false, true, false, 1>("MFMA + ds_read (1st half)", A, W, sink);
+    run<true, false, true, false, 2>("MFMA + ds_read (burst at top)", A, W, sink);
+    run<true, false, true, true, 1>("MFMA + ds_read (1st half) + barrier", A, W, sink);
+    run<true, true, true, true, 0>("MFMA + DMA + ds_read (2nd half) + barrier  [= gemm_big loop]", A, W, sink);
+    run<true, true, true, true, 1>("MFMA + DMA + ds_read (1st half) + barrier", A, W, sink);
+    run<true, true, true, false, 1>("MFMA + DMA + ds_read (1st half), no barrier", A, W, sink);
+    return 0;
+}
