@@ -460,7 +460,13 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
         return ok;
     };
     auto epilogue = [&]() {
-        if constexpr (EPI == EPI_STORE_T || EPI == EPI_GATE_T || EPI == EPI_ROPE_T) {
+        if constexpr (VAR == 30) {  // the launcher guarantees whole tiles and lean operand forms: no generic code in this build
+            if (p.act == ACT_GELU_TANH)
+                lean_epilogue(std::integral_constant<int, ACT_GELU_TANH>{});
+            else
+                lean_epilogue(std::integral_constant<int, ACT_NONE>{});
+            return;
+        } else if constexpr (EPI == EPI_STORE_T || EPI == EPI_GATE_T || EPI == EPI_ROPE_T) {
             if (p.lean_epi && lean_ok()) {
                 if (p.act == ACT_GELU_TANH)
                     lean_epilogue(std::integral_constant<int, ACT_GELU_TANH>{});
@@ -682,7 +688,9 @@ template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmPa
             const dim3 pg(nblocks < g_gemm_persist_grid ? nblocks : g_gemm_persist_grid);
             if (g_gemm_variant == 31) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI_GATE_T, 31, 5>), pg, block, 0, stream, p, tiles_n, nblocks);
             if (g_gemm_variant == 32) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI_GATE_T, 32, 5>), pg, block, 0, stream, p, tiles_n, nblocks);
-        } else if (g_gemm_variant == 30 && MODE == GEMM_DENSE)
+        } else if (g_gemm_variant == 30 && MODE == GEMM_DENSE && (EPI == EPI_STORE_T || EPI == EPI_GATE_T || EPI == EPI_ROPE_T) && p.M % 256 == 0 &&
+                   p.N % 256 == 0 && (p.ldo & 7) == 0 && p.bias && (p.act == ACT_NONE || p.act == ACT_GELU_TANH) &&
+                   (EPI != EPI_GATE_T || (p.gate_bstride == 0 && (!p.rowmask || p.rowbits))) && (EPI != EPI_ROPE_T || p.rows_per_batch >= 128))
             hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI, 30, 5>), dim3(nblocks < g_gemm_persist_grid ? nblocks : g_gemm_persist_grid), block, 0, stream, p, tiles_n, nblocks);
         else if (g_gemm_stages == 5)
             hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 1, 5>), grid, block, 0, stream, p, tiles_n, nblocks);

@@ -56,7 +56,6 @@ def _attn_ref(qkv, mask):
     return o.transpose(1, 2).reshape(qkv.shape[0], qkv.shape[1], -1).float()
 
 
-@pytest.mark.parametrize("prec", [P_FP32, P_BF16])
 def _fused_ref(epi, A, W, b, act, gate, rowmask, rope, rope_heads, seq):
     """fp64 restatement of the three fused store epilogues (oracle/cpu_ref.py: dit_block's linears, apply_rope)."""
     import gpu_helpers as G
@@ -120,6 +119,7 @@ def test_linear_fused_epilogues(knobs, epi_name, shape, seq):
         assert torch.count_nonzero(out[~rowmask]) == 0  # masked rows are exact zeros (modules.py:499-501)
 
 
+@pytest.mark.parametrize("prec", [P_FP32, P_BF16])
 @pytest.mark.parametrize("B,N,H,masked", [(2, 56, 2, True), (1, 41, 2, False), (2, 200, 3, True), (1, 64, 16, False)])
 def test_attention_reference_kernel(prec, B, N, H, masked):
     import gpu_helpers as G
