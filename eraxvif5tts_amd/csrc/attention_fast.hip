@@ -149,15 +149,21 @@ __global__ __launch_bounds__(256, 2) void attn_fast_kernel(const bf16_t* __restr
         const float m_new = fmaxf(m_run, mt * c);  // -inf * c stays -inf; m_run starts finite
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
-        float rs = 0.f;
+        // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32): two scores per VALU instruction; only the exp2 itself is scalar
+        const f32x2 c2 = {c, c}, nm2 = {-m_new, -m_new};
+        f32x2 rs2 = {0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][i], c, -m_new));
-                s[kb][i] = pv;
-                rs += pv;
+            for (int i = 0; i < 16; i += 2) {
+                f32x2 x = __builtin_elementwise_fma(f32x2{s[kb][i], s[kb][i + 1]}, c2, nm2);
+                x[0] = __builtin_amdgcn_exp2f(x[0]);
+                x[1] = __builtin_amdgcn_exp2f(x[1]);
+                s[kb][i] = x[0];
+                s[kb][i + 1] = x[1];
+                rs2 += x;
             }
+        const float rs = rs2[0] + rs2[1];
         l_run = l_run * alpha + rs;
         // the running max settles after the first tiles: skip the 32-register rescale when no query of this wave moved its max
         if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {
@@ -349,15 +355,20 @@ __global__ __launch_bounds__(256, 2) void attn_fast2_kernel(const bf16_t* __rest
             const float m_new = fmaxf(m_run[j], mt * c);
             const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);
             m_run[j] = m_new;
-            float rs = 0.f;
+            const f32x2 c2 = {c, c}, nm2 = {-m_new, -m_new};
+            f32x2 rs2 = {0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][kb][i], c, -m_new));
-                    s[j][kb][i] = pv;
-                    rs += pv;
+                for (int i = 0; i < 16; i += 2) {
+                    f32x2 x = __builtin_elementwise_fma(f32x2{s[j][kb][i], s[j][kb][i + 1]}, c2, nm2);
+                    x[0] = __builtin_amdgcn_exp2f(x[0]);
+                    x[1] = __builtin_amdgcn_exp2f(x[1]);
+                    s[j][kb][i] = x[0];
+                    s[j][kb][i + 1] = x[1];
+                    rs2 += x;
                 }
+            const float rs = rs2[0] + rs2[1];
             l_run[j] = l_run[j] * alpha + rs;
             if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {
 #pragma unroll
