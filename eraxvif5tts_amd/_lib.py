@@ -27,6 +27,11 @@ class VocosConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_mels", "dim", "inter_dim", "layers", "n_fft", "hop")]
 
 
+class DurationWeights(C.Structure):  # struct f5_duration_weights
+    _fields_ = [(n, C.c_void_p) for n in ("text_embed", "conv1_w", "conv1_b", "norm1_w", "norm1_b", "conv2_w", "conv2_b", "norm2_w", "norm2_b",
+                                          "proj_w", "proj_b")] + [(n, C.c_int32) for n in ("vocab_rows", "in_channels", "filter_channels", "kernel_size")]
+
+
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 _PROTOS = {
     "f5_last_error": (C.c_char_p, []),
@@ -47,6 +52,7 @@ _PROTOS = {
     "f5_plan_timing_end": (_I, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int), _P]),
     "f5_plan_set_tap": (_I, [_P, C.c_char_p, _P]),
     "f5_plan_set_option": (_I, [_P, C.c_char_p, _I]),
+    "f5_duration_predict": (_I, [C.POINTER(DurationWeights), _I, _I, _P, _I, _P, _P, _P, _P]),
     "f5_op_linear": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
     "f5_op_linear_fused": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P]),
     "f5_op_layernorm_modulate": (_I, [_I, _I, _P, _P, _P, _P, _P]),

@@ -24,7 +24,7 @@ import yaml
 
 from ..model import CFM
 from ..model import backbones as _backbones
-from ..model.utils import convert_char_to_pinyin, get_tokenizer
+from ..model.utils import convert_char_to_pinyin, get_tokenizer, list_str_to_idx
 from . import audio as _audio
 from .utils_infer import DEFAULT_VOCAB, chunk_text, cross_fade_concat, load_checkpoint, load_vocoder
 
@@ -80,6 +80,8 @@ class F5TTSWrapper:
         if self.use_duration_predictor and not self.has_duration_predictor:
             print("Warning: Duration predictor requested but not found in model. Using fallback duration calculation.")
             self.use_duration_predictor = False
+        elif self.has_duration_predictor:
+            print("Duration predictor found in model.")
 
         if vocoder is not None:  # plug point B: any object with .decode(mel[b, 100, T])
             self.vocoder = vocoder
@@ -138,6 +140,18 @@ class F5TTSWrapper:
     def calculate_duration_with_predictor(self, text_tokens, text_lengths, local_speed=1.0):
         raise NotImplementedError("the optional duration predictor is not part of this build (scope table row f.2)")
 
+    def calculate_duration_with_predictor(self, text_tokens, text_lengths, local_speed=1.0):
+        """Reference :381-406, op for op: token mask from the lengths, ``model.duration_predictor(tokens, mask)`` -> [b, 1, nt]
+        log-durations, ``exp(...).squeeze(-1).sum(dim=1)`` and ``durations[0].item()``.  (As in the reference the reduction runs
+        over the singleton channel axis, so ``.item()`` only succeeds for a one-token text; the quirk is kept, not repaired.)"""
+        b, nt = text_tokens.shape
+        range_tensor = torch.arange(nt, device=self.device).unsqueeze(0)
+        text_tokens_mask = (range_tensor < text_lengths.unsqueeze(1)).int()
+        with torch.inference_mode():
+            log_durations = self.model.duration_predictor(text_tokens, text_tokens_mask)
+            durations = torch.exp(log_durations).squeeze(-1).sum(dim=1)
+        return self.ref_audio_len + int(durations[0].item() / local_speed)
+
     # ------------------------------------------------------------------ synthesis
     def generate(self, text: str, output_path: Optional[str] = None, nfe_step: Optional[int] = None, cfg_strength: Optional[float] = None,
                  sway_sampling_coef: Optional[float] = None, speed: Optional[float] = None, fix_duration: Optional[float] = None,
@@ -151,6 +165,8 @@ class F5TTSWrapper:
         speed = speed if speed is not None else self.speed
         fix_duration = fix_duration if fix_duration is not None else self.fix_duration
         cross_fade_duration = cross_fade_duration if cross_fade_duration is not None else self.cross_fade_duration
+        use_predictor = use_duration_predictor if use_duration_predictor is not None else self.use_duration_predictor
+        can_use_predictor = use_predictor and self.has_duration_predictor
 
         audio_len = self.ref_audio_processed.shape[-1] / self.target_sample_rate
         max_chars = int(len(self.ref_text.encode("utf-8")) / audio_len * (22 - audio_len))
@@ -166,6 +182,14 @@ class F5TTSWrapper:
             if fix_duration is not None:
                 duration = int(fix_duration * self.target_sample_rate / self.hop_length)
                 print(f"Using fixed duration: {fix_duration}s ({duration} frames)")
+            elif can_use_predictor:
+                if isinstance(final_text_list[0], str):
+                    text_tokens = list_str_to_idx(final_text_list, self.vocab_char_map).to(self.device)
+                else:
+                    text_tokens = torch.tensor(final_text_list, device=self.device)
+                text_lengths = torch.tensor([len(t) for t in final_text_list], device=self.device)
+                duration = self.calculate_duration_with_predictor(text_tokens, text_lengths, local_speed)
+                print(f"Duration predictor output: {duration} frames")
             else:
                 ref_text_len, gen_text_len = len(self.ref_text.encode("utf-8")), len(text_batch.encode("utf-8"))
                 duration = self.ref_audio_len + int(self.ref_audio_len / ref_text_len * gen_text_len / local_speed)

@@ -131,6 +131,20 @@ int f5_plan_timing_end(f5_plan_t p, float* avg_ms, int* launches, f5_stream_t st
  * kernels wherever they support the problem (default).  Drops any captured graphs. */
 int f5_plan_set_option(f5_plan_t p, const char* key, int value);
 
+/* ------------------------------------------------------------------ duration predictor
+ * Replaces DurationPredictor.forward / .phoneme_forward (reference model/duration_predictor.py:28-46 / :48-68) as called from
+ * F5TTSWrapper.calculate_duration_with_predictor (infer/f5tts_wrapper.py:381-406).  All tensors f32 on the device, PyTorch layouts:
+ *   text_embed [vocab_rows, in_channels]; conv1_w [filter, in_channels, k]; conv2_w [filter, filter, k]; norm*_w/b [filter];
+ *   proj_w [filter] (the [1, filter, 1] Conv1d weight); proj_b [1].  gin_channels / g conditioning is not supported (the wrapper never passes g). */
+typedef struct f5_duration_weights {
+    const float *text_embed, *conv1_w, *conv1_b, *norm1_w, *norm1_b, *conv2_w, *conv2_b, *norm2_w, *norm2_b, *proj_w, *proj_b;
+    int32_t vocab_rows, in_channels, filter_channels, kernel_size;
+} f5_duration_weights;
+/* tokens i32 [batch, nt] (pad -1), add_one = 1 for forward() (ids shifted so that 0 is the filler), 0 for phoneme_forward();
+ * mask i32 [batch, nt] (1 = real token); scratch f32 [2 * batch * filter_channels * nt]; out f32 [batch, nt] = log-durations * mask. */
+int f5_duration_predict(const f5_duration_weights* w, int batch, int nt, const int32_t* tokens, int add_one, const int32_t* mask,
+                        float* scratch, float* out, f5_stream_t stream);
+
 /* ------------------------------------------------------------------ per-op entry points (parity tests, micro-benchmarks) */
 /* out[M,N] = A[M,K] @ W[N,K]^T + bias ; A/W/out f32 dev; computed through the precision's GEMM kernel
  * (bf16: inputs rounded to bf16 on device, MFMA, f32 accumulate).  act: 0 none, 1 gelu-tanh, 2 gelu-erf, 3 mish.

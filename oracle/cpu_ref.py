@@ -355,6 +355,24 @@ def vocos_decode(V, mel):
     return istft_center(mag * torch.cos(ph), mag * torch.sin(ph))
 
 
+# ----------------------------------------------------------------------------- duration predictor
+def duration_predictor(W, tokens, mask, add_one=True, prefix=""):
+    """DurationPredictor.forward (model/duration_predictor.py:28-46; phoneme_forward :48-68 with add_one=False):
+    Embedding(tokens+1) -> [Conv1d(k, pad k//2)(x*mask) -> relu -> GroupNorm(1 group: over all channels AND positions, eps 1e-5)] x2
+    -> Conv1d(F->1, 1)(x*mask) * mask.  Dropout is the identity at inference.  tokens [b, nt] (pad -1), mask [b, nt] -> [b, 1, nt]."""
+    F_ = torch.nn.functional
+    g = lambda n: W[prefix + n].float()
+    ids = tokens.long() + (1 if add_one else 0)
+    x = g("text_embed.weight")[ids].transpose(1, 2)  # [b, C, nt]
+    m = mask.float().unsqueeze(1)  # [b, 1, nt]
+    k = g("conv_1.weight").shape[-1]
+    for i in ("1", "2"):
+        x = F_.conv1d(x * m, g(f"conv_{i}.weight"), g(f"conv_{i}.bias"), padding=k // 2)
+        x = F_.group_norm(torch.relu(x), 1, g(f"norm_{i}.weight"), g(f"norm_{i}.bias"), eps=1e-5)
+    x = F_.conv1d(x * m, g("proj.weight"), g("proj.bias"))
+    return x * m
+
+
 # ----------------------------------------------------------------------------- synthetic weights
 def dit_param_shapes(cfg, vocab_size, mel_dim=100):
     """Names/shapes of DiT.state_dict() for a given arch dict."""

@@ -3,6 +3,7 @@ reference and against the CPU oracle.
 
 Stated tolerances (SURVEY.md 8c calibration: the reference model itself in plain bf16 deviates 1.1e-2..1.2e-2 rel-L2 from
 its own fp32 run): fp32 mode rel-L2 <= 2e-4 end to end; bf16 production mode rel-L2 <= 2e-2 on the generated frames."""
+import numpy as np
 import pytest
 import torch
 
@@ -130,3 +131,40 @@ def test_true_size_base_forward(prec):
     for drop, key in ((False, "out_c"), (True, "out_u")):
         out = m(x=x, cond=cond, text=text, time=t, mask=mask, drop_audio_cond=drop, drop_text=drop)
         assert rel_l2(out.cpu(), z[key]) < STAGE_TOL[prec], key
+
+
+# ----------------------------------------------------------------------------- duration predictor
+def _golden_duration_net():
+    from eraxvif5tts_amd.model import DurationPredictor
+    g = load_golden("duration_predictor")
+    net = DurationPredictor(text_num_embeds=int(g["text_num_embeds"]), in_channels=int(g["in_channels"]), filter_channels=int(g["filter_channels"]),
+                            kernel_size=int(g["kernel_size"]), p_dropout=0.5)
+    net.load_state_dict({k[2:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("w.")}, strict=True)
+    return g, net.eval().cuda()
+
+
+def test_duration_predictor_hip_matches_reference():
+    g, net = _golden_duration_net()
+    tokens, mask = torch.from_numpy(g["tokens"]).cuda(), torch.from_numpy(g["mask"]).cuda()
+    out = net(tokens, mask).cpu()
+    assert out.shape == g["out"].shape
+    assert rel_l2(out, torch.from_numpy(g["out"])) < 1e-5          # fp32 kernels vs the reference module's fp32 output
+    assert torch.count_nonzero(out[torch.from_numpy(g["mask"]).unsqueeze(1) == 0]) == 0
+    assert rel_l2(net.phoneme_forward(tokens.clamp(min=0), mask).cpu(), torch.from_numpy(g["out_phoneme"])) < 1e-5
+    assert rel_l2(net(tokens[2:3, :1], mask[2:3, :1]).cpu(), torch.from_numpy(g["out_one_token"])) < 1e-5
+    with pytest.raises(NotImplementedError):
+        net(tokens, mask, g=torch.zeros(4, 8, 1).cuda())
+
+
+def test_duration_predictor_larger_shapes_vs_oracle():
+    """Sizes a real predictor would have (text_dim 512, 256 filters, k = 5, 300 tokens) against the CPU oracle on seeded weights."""
+    from eraxvif5tts_amd.model import DurationPredictor
+    torch.manual_seed(11)
+    net = DurationPredictor(text_num_embeds=2545, in_channels=512, filter_channels=256, kernel_size=5, p_dropout=0.1).eval()
+    lens = torch.tensor([300, 151, 77])
+    tokens = torch.randint(0, 2545, (3, 300))
+    tokens = torch.where(torch.arange(300)[None, :] < lens[:, None], tokens, torch.full_like(tokens, -1))
+    mask = (torch.arange(300)[None, :] < lens[:, None]).int()
+    ref = cpu_ref.duration_predictor({k: v.detach() for k, v in net.state_dict().items()}, tokens, mask)
+    out = net.cuda()(tokens.cuda(), mask.cuda()).cpu()
+    assert rel_l2(out, ref) < 1e-5

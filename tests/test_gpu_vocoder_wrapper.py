@@ -128,3 +128,15 @@ def test_wrapper_end_to_end(tmp_path):
     assert rel_l2(got, ref_wave) < 1e-4
     out_path = os.path.join(str(tmp_path), "out", "gen.wav")
     assert tts.generate("short one.", output_path=out_path, nfe_step=2) == out_path and os.path.getsize(out_path) > 44
+    # duration predictor plug point (f5tts_wrapper.py:165-170, 381-406, 486-498): absent -> the flag is dropped with a warning ...
+    assert not tts.has_duration_predictor
+    from eraxvif5tts_amd.model import DurationPredictor
+    torch.manual_seed(3)
+    tts.model.duration_predictor = DurationPredictor(text_num_embeds=V, in_channels=16, filter_channels=24, kernel_size=3, p_dropout=0.1).eval().cuda()
+    tts.has_duration_predictor = True
+    # ... present: ref_audio_len + int(exp(log_duration) / speed), exactly the reference's arithmetic (one token: the only case its .item() accepts)
+    tok, ln = torch.tensor([[5]], device="cuda"), torch.tensor([1], device="cuda")
+    logd = cpu_ref.duration_predictor({k: v.detach().cpu() for k, v in tts.model.duration_predictor.state_dict().items()}, tok.cpu(), torch.ones(1, 1))
+    assert tts.calculate_duration_with_predictor(tok, ln, local_speed=0.5) == tts.ref_audio_len + int(float(torch.exp(logd)) / 0.5)
+    with pytest.raises((RuntimeError, ValueError)):  # the reference's reduction leaves [nt] values: .item() refuses more than one token
+        tts.calculate_duration_with_predictor(torch.tensor([[5, 6, 7]], device="cuda"), torch.tensor([3], device="cuda"))

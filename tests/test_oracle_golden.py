@@ -93,3 +93,14 @@ def test_mel_and_istft_consistency():
     ref = torch.istft(torch.complex(re, im), 1024, hop_length=256, win_length=1024, window=torch.hann_window(1024), center=True)
     assert mine.shape == ref.shape == (2, (T - 1) * 256)
     assert torch.allclose(mine, ref, atol=1e-5)
+
+
+def test_duration_predictor_matches_reference_fixture():
+    """oracle/cpu_ref.duration_predictor vs the reference DurationPredictor's own outputs (tests/golden/duration_predictor.npz)."""
+    g = load_golden("duration_predictor")
+    W = {k[2:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("w.")}
+    tokens, mask = torch.from_numpy(g["tokens"]), torch.from_numpy(g["mask"])
+    assert rel_l2(cpu_ref.duration_predictor(W, tokens, mask), torch.from_numpy(g["out"])) < 2e-6
+    assert rel_l2(cpu_ref.duration_predictor(W, tokens.clamp(min=0), mask, add_one=False), torch.from_numpy(g["out_phoneme"])) < 2e-6
+    assert rel_l2(cpu_ref.duration_predictor(W, tokens[2:3, :1], mask[2:3, :1]), torch.from_numpy(g["out_one_token"])) < 2e-6
+    assert torch.count_nonzero(torch.from_numpy(g["out"])[mask.unsqueeze(1) == 0]) == 0  # padded tokens carry no duration
