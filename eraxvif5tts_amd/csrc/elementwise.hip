@@ -7,10 +7,13 @@
 // x[r] (+= y[r], written back) -> out[r] = LN(x[r]) * (add_one + mul[b]) + add[b].  The optional y is the previous
 // residual branch (gate * (attention | feed-forward) output in the activation dtype): folding the fp32 residual add into
 // this streaming pass keeps the GEMM epilogues store-only and the read-modify-write fully coalesced.
-template <typename TO, int MAXV, bool HAS_Y>
+// YMODE: 0 = x only; 1 = x += y, written back; 2 = (x + y) normalised but x NOT written back (the add is repeated by the next pass);
+//        3 = x = (x + y) + y2, written back.  Modes 2 + 3 alternate inside a DiT block: the fp32 residual stream is written once per
+//        block instead of twice, with bit-identical sums (same operands, same order).
+template <typename TO, int MAXV, int YMODE>
 __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, int ldx, int rows, int dim, const TO* __restrict__ y, int ldy,
-                                                        const float* __restrict__ mul, const float* __restrict__ add, int mod_bstride,
-                                                        int rows_per_batch, float add_one, TO* __restrict__ out, int ldo) {
+                                                        const TO* __restrict__ y2, const float* __restrict__ mul, const float* __restrict__ add,
+                                                        int mod_bstride, int rows_per_batch, float add_one, TO* __restrict__ out, int ldo) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -18,20 +21,23 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, i
     const int nvec = dim >> 2;  // dim % 4 == 0
     f32x4 v[MAXV];
     float s = 0.f;
+    auto load_y = [&](const TO* yr) {
+        if constexpr (sizeof(TO) == 2) {
+            const bf16x4 y4 = *reinterpret_cast<const bf16x4*>(yr);
+            return f32x4{(float)y4[0], (float)y4[1], (float)y4[2], (float)y4[3]};
+        } else {
+            return *reinterpret_cast<const f32x4*>(yr);
+        }
+    };
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + i * 64;
         if (c < nvec) {
             v[i] = *reinterpret_cast<const f32x4*>(xr + c * 4);
-            if constexpr (HAS_Y) {
-                const TO* yr = y + (size_t)row * ldy + c * 4;
-                if constexpr (sizeof(TO) == 2) {
-                    const bf16x4 y4 = *reinterpret_cast<const bf16x4*>(yr);
-                    v[i] += f32x4{(float)y4[0], (float)y4[1], (float)y4[2], (float)y4[3]};
-                } else {
-                    v[i] += *reinterpret_cast<const f32x4*>(yr);
-                }
-                *reinterpret_cast<f32x4*>(xr + c * 4) = v[i];
+            if constexpr (YMODE != 0) {
+                v[i] += load_y(y + (size_t)row * ldy + c * 4);
+                if constexpr (YMODE == 3) v[i] += load_y(y2 + (size_t)row * ldy + c * 4);
+                if constexpr (YMODE != 2) *reinterpret_cast<f32x4*>(xr + c * 4) = v[i];
             }
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
@@ -71,37 +77,49 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, i
 }
 
 template <typename TO, int MAXV>
-static void ln_launch(float* x, int ldx, int rows, int dim, const void* y, int ldy, const float* mul, const float* add, int mod_bstride,
-                      int rows_per_batch, float one, void* out, int ldo, hipStream_t stream) {
+static void ln_launch(float* x, int ldx, int rows, int dim, const void* y, int ldy, const void* y2, int ymode, const float* mul, const float* add,
+                      int mod_bstride, int rows_per_batch, float one, void* out, int ldo, hipStream_t stream) {
     dim3 grid(cdiv(rows, 4)), block(256);
-    if (y)
-        hipLaunchKernelGGL((layernorm_kernel<TO, MAXV, true>), grid, block, 0, stream, x, ldx, rows, dim, (const TO*)y, ldy, mul, add, mod_bstride,
-                           rows_per_batch, one, (TO*)out, ldo);
-    else
-        hipLaunchKernelGGL((layernorm_kernel<TO, MAXV, false>), grid, block, 0, stream, x, ldx, rows, dim, (const TO*)nullptr, 0, mul, add,
-                           mod_bstride, rows_per_batch, one, (TO*)out, ldo);
+#define F5_LN_CASE(M)                                                                                                                  \
+    hipLaunchKernelGGL((layernorm_kernel<TO, MAXV, M>), grid, block, 0, stream, x, ldx, rows, dim, (const TO*)y, ldy, (const TO*)y2, mul, add, \
+                       mod_bstride, rows_per_batch, one, (TO*)out, ldo)
+    if (ymode == 0) F5_LN_CASE(0);
+    else if (ymode == 1) F5_LN_CASE(1);
+    else if (ymode == 2) F5_LN_CASE(2);
+    else F5_LN_CASE(3);
+#undef F5_LN_CASE
 }
 
-int launch_layernorm_add(int precision_out, float* x, int ldx, int rows, int dim, const void* y, int ldy, const float* mul, const float* add,
-                         int mod_bstride, int rows_per_batch, int add_one, void* out, int ldo, hipStream_t stream) {
+// ymode (see layernorm_kernel): 1 = x += y (written back), 2 = normalise x + y without writing x, 3 = x = (x + y) + y2 (written back)
+int launch_layernorm_add2(int precision_out, float* x, int ldx, int rows, int dim, const void* y, int ldy, const void* y2, int ymode,
+                          const float* mul, const float* add, int mod_bstride, int rows_per_batch, int add_one, void* out, int ldo,
+                          hipStream_t stream) {
     if (rows <= 0) return 0;
     if (dim % 4 != 0 || dim > 2048 || (ldx & 3) || (ldo & 3) || (mod_bstride & 3) || (y && (ldy & 3)))
         return f5_fail(F5_EINVAL, "layernorm: dim=%d unsupported", dim);
+    if (!y) ymode = 0;
+    if (ymode < 0 || ymode > 3 || (ymode == 3 && !y2)) return f5_fail(F5_EINVAL, "layernorm: bad residual mode %d", ymode);
     if (rows_per_batch <= 0) rows_per_batch = rows;
     const float one = add_one ? 1.0f : 0.0f;
     if (precision_out == F5_PREC_BF16) {
         if (dim <= 1024)
-            ln_launch<bf16_t, 4>(x, ldx, rows, dim, y, ldy, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream);
+            ln_launch<bf16_t, 4>(x, ldx, rows, dim, y, ldy, y2, ymode, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream);
         else
-            ln_launch<bf16_t, 8>(x, ldx, rows, dim, y, ldy, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream);
+            ln_launch<bf16_t, 8>(x, ldx, rows, dim, y, ldy, y2, ymode, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream);
     } else {
         if (dim <= 1024)
-            ln_launch<float, 4>(x, ldx, rows, dim, y, ldy, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream);
+            ln_launch<float, 4>(x, ldx, rows, dim, y, ldy, y2, ymode, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream);
         else
-            ln_launch<float, 8>(x, ldx, rows, dim, y, ldy, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream);
+            ln_launch<float, 8>(x, ldx, rows, dim, y, ldy, y2, ymode, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream);
     }
     F5_LAUNCH_CHECK();
     return 0;
+}
+
+int launch_layernorm_add(int precision_out, float* x, int ldx, int rows, int dim, const void* y, int ldy, const float* mul, const float* add,
+                         int mod_bstride, int rows_per_batch, int add_one, void* out, int ldo, hipStream_t stream) {
+    return launch_layernorm_add2(precision_out, x, ldx, rows, dim, y, ldy, nullptr, 1, mul, add, mod_bstride, rows_per_batch, add_one, out, ldo,
+                                 stream);
 }
 
 int launch_layernorm(int precision_out, const float* x, int ldx, int rows, int dim, const float* mul, const float* add, int mod_bstride,

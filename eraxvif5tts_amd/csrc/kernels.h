@@ -16,6 +16,10 @@ int launch_layernorm(int precision_out /*F5_PREC_* of `out`*/, const float* x, i
 // same with the fp32 residual add fused in: x[r] += y[r] (y in the activation dtype, may be null) is written back first
 int launch_layernorm_add(int precision_out, float* x, int ldx, int rows, int dim, const void* y, int ldy, const float* mul, const float* add,
                          int mod_bstride, int rows_per_batch, int add_one, void* out, int ldo, hipStream_t stream);
+// ymode 1: x += y (written back); 2: normalise x + y, x untouched; 3: x = (x + y) + y2 (written back)
+int launch_layernorm_add2(int precision_out, float* x, int ldx, int rows, int dim, const void* y, int ldy, const void* y2, int ymode,
+                          const float* mul, const float* add, int mod_bstride, int rows_per_batch, int add_one, void* out, int ldo,
+                          hipStream_t stream);
 // depthwise Conv1d(k=7, pad=3) along the sequence (+bias) then LayerNorm(eps 1e-6, affine) -> activation dtype
 // x f32 [B*N, C]; wt f32 [7][C] (tap-major); out [B*N, C]
 int launch_dwconv7_ln(int precision_out, const float* x, int B, int N, int C, const float* wt, const float* cbias, const float* ln_w,

@@ -64,6 +64,7 @@ struct f5_plan_s {
     float *xres = nullptr, *base = nullptr, *vout = nullptr, *mod = nullptr, *temb = nullptr, *tsin = nullptr, *thid = nullptr;
     float *tvals = nullptr, *coefs = nullptr, *te[2] = {nullptr, nullptr}, *grn_scratch = nullptr, *traj = nullptr, *xmid = nullptr;
     float *cond_in = nullptr, *rope = nullptr, *tap_scratch = nullptr;
+    void *yA = nullptr;  // attention-branch output when the residual write is deferred (dit_eval)
     void *hT = nullptr, *cT = nullptr, *yT = nullptr, *qkv = nullptr, *ffh = nullptr, *abase = nullptr, *xin = nullptr, *teT = nullptr, *te_h = nullptr;
     uint8_t *filler = nullptr, *mask = nullptr, *rowbits = nullptr;
     const uint8_t* rowbits_src = nullptr;  // the row mask `rowbits` was built from (GemmParams::rowbits)
@@ -348,6 +349,7 @@ extern "C" int f5_plan_create(f5_model_t m, int max_batch, int max_seq, int max_
         if ((rc = A.alloc(&p->hT, rows * D * es))) break;
         if ((rc = A.alloc(&p->cT, rows * std::max(D, inner) * es))) break;
         if ((rc = A.alloc(&p->yT, rows * D * es))) break;
+        if ((rc = A.alloc(&p->yA, rows * D * es))) break;
         if ((rc = A.alloc(&p->qkv, rows * 3 * inner * es))) break;
         if ((rc = A.alloc(&p->ffh, rows * ff * es))) break;
         if ((rc = A.alloc(&p->abase, rows * (MELP + td) * es))) break;
@@ -464,6 +466,8 @@ extern "C" int f5_plan_set_tap(f5_plan_t p, const char* stage, float* dst) {
 }
 
 // ----------------------------------------------------------------------------- helpers
+int g_ln_defer = 1;  // tuning knob ("ln_defer"): write the fp32 residual stream once per DiT block (0 = after every LayerNorm pass)
+
 static GemmParams gp_zero() {
     GemmParams g;
     memset(&g, 0, sizeof(g));
@@ -570,12 +574,15 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         F5_TRY(run_gemm(p, g, GEMM_CONV31, li == 0 ? EPI_STORE_T : EPI_GATE_T, st));
     }
 
+    const bool defer = p->taps.empty() && g_ln_defer;
     for (int l = 0; l < c.depth; ++l) {
         const BlockW& b = m->blocks[l];
         const float* ml = modp + (size_t)l * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp (modules.py:312)
         const std::string tn = "blk" + std::to_string(l);
         // x += (conv branch | previous block's gated FF output); n1 = LN(x) * (1 + scale_msa) + shift_msa
-        F5_TRY(launch_layernorm_add(P, p->xres, D, rows, D, p->yT, D, ml + D, ml, mod_bstride, N, 1, p->hT, D, st));
+        // With no stage tap set, the fp32 residual stream is written once per block: this pass normalises x + y without storing it,
+        // the second LayerNorm of the block repeats the add (same operands, same order: bit-identical) and stores x + y + y_attn.
+        F5_TRY(launch_layernorm_add2(P, p->xres, D, rows, D, p->yT, D, nullptr, defer ? 2 : 1, ml + D, ml, mod_bstride, N, 1, p->hT, D, st));
         if (l == 0) F5_TRY(tap_f32(p, "input_embed", p->xres, D, rows, D, st));
         if (l > 0) F5_TRY(tap_f32(p, "blk" + std::to_string(l - 1) + ".out", p->xres, D, rows, D, st));
         F5_TRY(tap_t(p, tn + ".n1", p->hT, D, rows, D, st));
@@ -605,12 +612,13 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         // y = gate_msa * to_out(attn), 0 on padded query rows (modules.py:499-501, 635)
         g = gp_zero();
         g.A = p->cT; g.lda = inner; g.W = b.w_o; g.ldw = inner; g.M = rows; g.N = D; g.K = inner;
-        g.bias = b.b_o; g.out_t = p->yT; g.ldo = D; g.gate = ml + 2 * D; g.gate_bstride = mod_bstride; g.rows_per_batch = N;
+        g.bias = b.b_o; g.out_t = defer ? p->yA : p->yT; g.ldo = D; g.gate = ml + 2 * D; g.gate_bstride = mod_bstride; g.rows_per_batch = N;
         g.rowmask = mask;
         g.rowbits = (mask && mask == p->rowbits_src) ? p->rowbits : nullptr;
         F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_GATE_T, st));
         // x += y; n2 = LN(x) * (1 + scale_mlp) + shift_mlp
-        F5_TRY(launch_layernorm_add(P, p->xres, D, rows, D, p->yT, D, ml + 4 * D, ml + 3 * D, mod_bstride, N, 1, p->hT, D, st));
+        F5_TRY(launch_layernorm_add2(P, p->xres, D, rows, D, p->yT, D, defer ? p->yA : nullptr, defer ? 3 : 1, ml + 4 * D, ml + 3 * D, mod_bstride, N, 1,
+                                     p->hT, D, st));
         g = gp_zero();
         g.A = p->hT; g.lda = D; g.W = b.w_ff1; g.ldw = D; g.M = rows; g.N = ff; g.K = D;
         g.bias = b.b_ff1; g.act = ACT_GELU_TANH; g.out_t = p->ffh; g.ldo = ff;
