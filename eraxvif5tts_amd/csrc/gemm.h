@@ -59,3 +59,6 @@ bool gemm_fast_supported(const GemmParams& p, int precision, int mode, int epi);
 // 4-wave kernel with 128 x 128 outputs per wave (gemm_big.hip): the DiT block linears with whole-feature-tile shapes
 bool gemm_big_supported(const GemmParams& p, int mode, int epi);
 int launch_gemm_big(const GemmParams& p, int epi, hipStream_t stream);
+// dedicated kernel for the dim-1024 grouped Conv1d(k = 31) of ConvPositionEmbedding (conv31.hip); GemmParams as for GEMM_CONV31
+bool conv31_supported(const GemmParams& p, int precision, int epi);
+int launch_conv31(const GemmParams& p, hipStream_t stream);

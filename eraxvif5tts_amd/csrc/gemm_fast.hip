@@ -724,6 +724,7 @@ bool gemm_fast_supported(const GemmParams& p, int precision, int mode, int epi) 
 int launch_gemm_fast(const GemmParams& p, int mode, int epi, hipStream_t stream) {
     if (g_gemm_variant == 1 && gemm_big_supported(p, mode, epi)) return launch_gemm_big(p, epi, stream);
     if (mode == GEMM_CONV31) {
+        if (conv31_supported(p, F5_PREC_BF16, epi)) return launch_conv31(p, stream);
         if (epi == EPI_STORE_T) return launch_fast<64, 32, GEMM_CONV31, EPI_STORE_T>(p, stream);
         if (epi == EPI_GATE_T) return launch_fast<64, 32, GEMM_CONV31, EPI_GATE_T>(p, stream);
         return f5_fail(F5_EINVAL, "gemm_fast(conv31): unsupported epilogue %d", epi);

@@ -108,6 +108,8 @@ extern "C" int f5_op_attention(int precision, int kernel, int B, int N, int H, c
     return sync_and_release(a, st, rc);
 }
 
+int g_op_conv_kernel = 0;  // tuning knob ("op_conv_kernel"): f5_op_conv_pos_embed runs the tuned conv kernels (bf16)
+
 extern "C" int f5_op_conv_pos_embed(int precision, int B, int N, int dim, const float* x, const float* w0, const float* b0, const float* w1,
                                     const float* b1, float* out, f5_stream_t stream) {
     F5_TRY(f5_check_device());
@@ -149,7 +151,17 @@ extern "C" int f5_op_conv_pos_embed(int precision, int B, int N, int dim, const 
         memset(&g, 0, sizeof(g));
         g.A = xt; g.lda = dim; g.W = wr[0]; g.M = rows; g.N = dim; g.K = 31 * win; g.bias = b0; g.act = ACT_MISH;
         g.rows_per_batch = N; g.conv_cg = cg; g.conv_win = win; g.out_t = c1; g.ldo = dim;
-        if ((rc = launch_gemm(g, precision, GEMM_CONV31, EPI_STORE_T, 0, st))) break;
+        // tuning knob "op_conv_kernel" = 1: the tuned kernels exactly as dit_eval launches them (store-only second conv, bf16 only)
+        const int kind = (g_op_conv_kernel && precision == F5_PREC_BF16 && gemm_fast_supported(g, precision, GEMM_CONV31, EPI_STORE_T)) ? 1 : 0;
+        if ((rc = launch_gemm(g, precision, GEMM_CONV31, EPI_STORE_T, kind, st))) break;
+        if (kind) {
+            void* c2 = nullptr;
+            if ((rc = a.alloc(&c2, (size_t)rows * dim * es))) break;
+            g.A = c1; g.W = wr[1]; g.bias = b1; g.out_t = c2;
+            if ((rc = launch_gemm(g, precision, GEMM_CONV31, EPI_GATE_T, 1, st))) break;
+            rc = launch_convert_back(precision, c2, dim, rows, dim, out, dim, st);
+            break;
+        }
         g.A = c1; g.W = wr[1]; g.bias = b1; g.out_t = nullptr; g.out_f = acc; g.ldof = dim;
         if ((rc = launch_gemm(g, precision, GEMM_CONV31, EPI_RESID, 0, st))) break;
         rc = launch_convert_back(F5_PREC_FP32, acc, dim, rows, dim, out, dim, st);
@@ -271,7 +283,7 @@ extern "C" int f5_bench_attention(int kernel, int B, int N, int H, int iters, fl
     return sync_and_release(a, st, rc);
 }
 
-extern int g_gemm_variant, g_gemm_stages, g_gemm_group, g_gemm_persist_grid, g_gemm_lean, g_gemm_nt, g_gemm_big, g_gemm_big_ablate, g_ln_defer, g_attn_ablate, g_attn_variant;
+extern int g_gemm_variant, g_gemm_stages, g_gemm_group, g_gemm_persist_grid, g_gemm_lean, g_gemm_nt, g_gemm_big, g_gemm_big_ablate, g_ln_defer, g_conv31, g_attn_ablate, g_attn_variant;
 extern "C" int f5_tuning_set(const char* key, int value) {
     if (!key) return f5_fail(F5_EINVAL, "null key");
     if (strcmp(key, "gemm_variant") == 0) {
@@ -288,6 +300,14 @@ extern "C" int f5_tuning_set(const char* key, int value) {
     }
     if (strcmp(key, "gemm_group") == 0) {
         g_gemm_group = value;
+        return 0;
+    }
+    if (strcmp(key, "op_conv_kernel") == 0) {
+        g_op_conv_kernel = value != 0;
+        return 0;
+    }
+    if (strcmp(key, "conv31") == 0) {
+        g_conv31 = value != 0;
         return 0;
     }
     if (strcmp(key, "ln_defer") == 0) {

@@ -156,6 +156,36 @@ def test_conv_pos_embed(prec, dim, B, N):
     assert rel_l2(out, ref) < (3e-6 if prec == P_FP32 else 4e-3)
 
 
+@pytest.mark.parametrize("conv31", [1, 0], ids=["halo_tile_kernel", "implicit_gemm"])
+@pytest.mark.parametrize("dim,B,N", [(1024, 2, 70), (1024, 3, 256), (1024, 1, 700), (1024, 2, 1000), (128, 2, 300)])
+def test_conv_pos_embed_tuned_kernels(conv31, dim, B, N):
+    """The two tuned forms of the grouped Conv1d(k=31)+Mish pair: conv31.hip (dim 1024: 64 channels per group) and the implicit GEMM of
+    gemm_fast.hip, against the oracle and against the reference tile kernel.  Ragged last tiles, utterance edges (zero padding) and
+    several utterances per launch are all in these shapes."""
+    import gpu_helpers as G
+    from eraxvif5tts_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(dim + N)
+    x = G.bf16_round(torch.randn(B, N, dim, generator=g))
+    cg = dim // 16
+    w0, w1 = [G.bf16_round(torch.randn(dim, cg, 31, generator=g) / math.sqrt(cg * 31)) for _ in range(2)]
+    b0, b1 = torch.randn(dim, generator=g) * 0.1, torch.randn(dim, generator=g) * 0.1
+    W = {"input_embed.conv_pos_embed.conv1d.0.weight": w0, "input_embed.conv_pos_embed.conv1d.0.bias": b0,
+         "input_embed.conv_pos_embed.conv1d.2.weight": w1, "input_embed.conv_pos_embed.conv1d.2.bias": b1}
+    ref = cpu_ref.conv_pos_embed(W, x)
+    base = G.op_conv_pos(P_BF16, x, w0, b0, w1, b1)
+    try:
+        _lib.check(lib.f5_tuning_set(b"op_conv_kernel", 1))
+        _lib.check(lib.f5_tuning_set(b"conv31", conv31))
+        out = G.op_conv_pos(P_BF16, x, w0, b0, w1, b1)
+    finally:
+        _lib.check(lib.f5_tuning_set(b"op_conv_kernel", 0))
+        _lib.check(lib.f5_tuning_set(b"conv31", 1))
+    assert rel_l2(base, ref) < 4e-3  # the intermediate activation between the two convolutions is rounded to bf16
+    assert rel_l2(out, ref) < 6e-3   # ... and so is the stored branch of the tuned path
+    assert rel_l2(out, base) < 4e-3
+
+
 # ----------------------------------------------------------------------------- tuned kernels (bf16) vs the same references
 @pytest.mark.parametrize("shape", [(256, 256, 64), (512, 1024, 1024), (300, 3072, 128), (1000, 100, 1024), (2048, 2048, 2048), (77, 512, 640)])
 @pytest.mark.parametrize("act", ["none", "gelu_tanh"])
