@@ -190,7 +190,7 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
             const int n = n0 + wn * WN + i * 16 + 4 * fq;
             okn[i] = n + 3 < p.N;  // N % 4 == 0: a lane's 4 features are valid together
             ncol[i] = okn[i] ? n : 0;
-            bias4[i] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ncol[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (VAR != 30) bias4[i] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ncol[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (EPI == EPI_GATE_T || EPI == EPI_RESID)
                 gate4[i] = (p.gate && p.gate_bstride == 0) ? *reinterpret_cast<const f32x4*>(p.gate + ncol[i]) : f32x4{1.f, 1.f, 1.f, 1.f};
         }
@@ -207,13 +207,15 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
     prep_epilogue();
 
     f32x4 acc[NI][MI];
-    auto zero_acc = [&]() {
+    // Every accumulator starts from the bias of its feature (all kernel variants and tile widths alike, so that the fp32 sums --
+    // and with them the bf16 outputs -- do not depend on which variant a batch size selects).  Called AFTER the first DMA issue:
+    // waiting for the bias loads must not delay the operand fetch.
+    auto init_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < MI; ++j) acc[i][j] = bias4[i];
     };
-    zero_acc();
 
     auto read_frags = [&](int kt, bf16x8 (&wf)[NI], bf16x8 (&af)[MI]) {
         if constexpr (VAR == 20 || VAR == 21) {
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
             f32x4 vals[NI];
             static_for<NI>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                f32x4 v = acc[i][j0 + jj] + bias4[i];
+                f32x4 v = acc[i][j0 + jj];  // bias: see init_acc
                 if constexpr (EPI == EPI_STORE_T || EPI == EPI_STORE_F32 || EPI == EPI_GATE_T || EPI == EPI_RESID) {
                     if (p.act == ACT_GELU_TANH) {
 #pragma unroll
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
             f32x4 vals[NI];
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                f32x4 v = acc[i][j] + bias4[i];
+                f32x4 v = acc[i][j];
                 if constexpr (ACT == ACT_GELU_TANH) {
                     constexpr float a = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
                     const f32x4 u = v * __builtin_elementwise_fma(v * v, f32x4{a * 0.044715f, a * 0.044715f, a * 0.044715f, a * 0.044715f}, f32x4{a, a, a, a});
@@ -505,19 +507,43 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
                 }
             }
         };
+        // VAR 30: the bias is folded into the accumulator start value and is not kept during the main loop (register budget: 128
+        // accumulators + 48 fragments + 16 gate + addresses); the next tile's bias is fetched under the epilogue.
+        auto load_bias = [&](int tn0, f32x4 (&dst)[NI]) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) dst[i] = *reinterpret_cast<const f32x4*>(p.bias + tn0 + wn * WN + i * 16 + 4 * fq);
+        };
+        auto acc_from = [&](const f32x4 (&b4)[NI]) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < MI; ++j) acc[i][j] = b4[i];
+        };
+        [[maybe_unused]] f32x4 b0[NI];
+        if constexpr (VAR == 30) load_bias(n0, b0);
 #pragma unroll
         for (int d = 0; d < D; ++d)
             if (gi < total) issue_next();
+        if constexpr (VAR == 30)
+            acc_from(b0);
+        else
+            init_acc();
         wait_pieces(min(D - 1, total - 1));
         __builtin_amdgcn_s_barrier();
         const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
         int g = 0, slot_c = 0;
         bf16x8 wf[NI], af[MI];
+        int nm0 = 0, nn0 = 0;
         for (int t = 0; t < my_tiles; ++t) {
             if (t > 0) {
-                tile_mn(blockIdx.x + t * G, m0, n0);
+                if constexpr (VAR == 30) {
+                    m0 = nm0;
+                    n0 = nn0;
+                } else {
+                    tile_mn(blockIdx.x + t * G, m0, n0);
+                }
                 prep_epilogue();
-                zero_acc();
+                if constexpr (VAR != 30) init_acc();
             }
             if (late) __builtin_amdgcn_s_barrier();
             for (int kt = 0; kt < nk; ++kt) {
@@ -537,7 +563,18 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
                 slot_c = slot_c + 1 == NSTAGE ? 0 : slot_c + 1;
             }
             if (!late) __builtin_amdgcn_s_barrier();  // same barrier count for both groups; both now store together
-            epilogue();
+            if constexpr (VAR == 30) {
+                f32x4 bn[NI];
+                const bool more = t + 1 < my_tiles;
+                if (more) {
+                    tile_mn(blockIdx.x + (t + 1) * G, nm0, nn0);
+                    load_bias(nn0, bn);
+                }
+                epilogue();
+                if (more) acc_from(bn);
+            } else {
+                epilogue();
+            }
         }
         return;
     }
@@ -551,6 +588,7 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
         for (int d = 0; d < D; ++d)
             if (d < nk) issue(d);
     }
+    init_acc();
     if constexpr (VAR == 2)
         wait_pieces(2);  // pair (2, 3) may be in flight (and, harmlessly waited for, the last piece of K-step 1)
     else if constexpr (HS)
@@ -651,7 +689,19 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
 
 int g_gemm_variant = 1;  // tuning knob (f5_tuning_set("gemm_variant", v)): 0 = plain ring, 1 = ring + staggered wave groups, 10-12 ablations
 int g_gemm_group = 8;    // tuning knob ("gemm_group"): token tiles per L2 patch (1 = feature-tile-fastest order)
-int g_gemm_persist_grid = 256;  // tuning knob ("gemm_persist_grid"): blocks of the persistent kernel (one per CU)
+int g_gemm_persist_grid = 0;  // tuning knob ("gemm_persist_grid"): workgroups of the persistent kernel (0 = one per CU of the device)
+int g_gemm_persist = 1;       // tuning knob ("gemm_persist"): 1 = whole-tile block linears run on the persistent grid
+static int persist_grid() {
+    if (g_gemm_persist_grid > 0) return g_gemm_persist_grid;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n & ~7;  // a multiple of the 8 XCDs keeps a workgroup's tiles on one XCD
+        if (cus < 8) cus = 8;
+    }
+    return cus;
+}
 int g_gemm_lean = 1;   // tuning knob ("gemm_lean"): 1 = lean epilogue on whole tiles, 0 = generic epilogue everywhere
 int g_gemm_nt = 0;     // tuning knob ("gemm_nt"): bit e = lean epilogue e (GemmEpi) uses non-temporal stores
 int g_gemm_stages = 5;   // tuning knob ("gemm_stages"): LDS ring slots of the 256x256 tile (4 = 128 KiB, 5 = 160 KiB = the whole LDS)
@@ -664,6 +714,11 @@ template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmPa
     const int tiles_m = cdiv(p.M, 256), tiles_n = cdiv(p.N, BN);
     const int nblocks = tiles_m * tiles_n;
     dim3 grid(nblocks), block(512);
+    // persistent grid (one workgroup per CU walking tiles, next tile's first K-steps prefetched under the epilogue, bias folded into the
+    // accumulator start): whole tiles with the lean epilogue's operand forms only
+    const bool persist_ok = MODE == GEMM_DENSE && (EPI == EPI_STORE_T || EPI == EPI_GATE_T || EPI == EPI_ROPE_T) && p.M % 256 == 0 &&
+                            p.N % 256 == 0 && (p.ldo & 7) == 0 && p.bias && p.out_t && (p.act == ACT_NONE || p.act == ACT_GELU_TANH) &&
+                            (EPI != EPI_GATE_T || (p.gate_bstride == 0 && (!p.rowmask || p.rowbits))) && (EPI != EPI_ROPE_T || p.rows_per_batch >= 128);
     if constexpr (BN == 256) {
         if (g_gemm_variant == 0)
             hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 0, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
@@ -688,10 +743,9 @@ template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmPa
             const dim3 pg(nblocks < g_gemm_persist_grid ? nblocks : g_gemm_persist_grid);
             if (g_gemm_variant == 31) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI_GATE_T, 31, 5>), pg, block, 0, stream, p, tiles_n, nblocks);
             if (g_gemm_variant == 32) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI_GATE_T, 32, 5>), pg, block, 0, stream, p, tiles_n, nblocks);
-        } else if (g_gemm_variant == 30 && MODE == GEMM_DENSE && (EPI == EPI_STORE_T || EPI == EPI_GATE_T || EPI == EPI_ROPE_T) && p.M % 256 == 0 &&
-                   p.N % 256 == 0 && (p.ldo & 7) == 0 && p.bias && (p.act == ACT_NONE || p.act == ACT_GELU_TANH) &&
-                   (EPI != EPI_GATE_T || (p.gate_bstride == 0 && (!p.rowmask || p.rowbits))) && (EPI != EPI_ROPE_T || p.rows_per_batch >= 128))
-            hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI, 30, 5>), dim3(nblocks < g_gemm_persist_grid ? nblocks : g_gemm_persist_grid), block, 0, stream, p, tiles_n, nblocks);
+        } else if ((g_gemm_variant == 30 || (g_gemm_variant == 1 && g_gemm_persist)) && persist_ok)
+            hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI, 30, 5>), dim3(nblocks < persist_grid() ? nblocks : persist_grid()), block, 0,
+                               stream, p, tiles_n, nblocks);
         else if (g_gemm_stages == 5)
             hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 1, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
         else

@@ -84,7 +84,8 @@ def _fused_ref(epi, A, W, b, act, gate, rowmask, rope, rope_heads, seq):
 
 
 # whole-tile shapes (lean epilogue), ragged rows / narrow tiles (generic epilogue), >= 160 tiles (where the 4-wave kernel applies)
-@pytest.mark.parametrize("knobs", [{}, {"gemm_lean": 0}, {"gemm_big": 1}], ids=["default", "generic_epilogue", "four_wave_kernel"])
+@pytest.mark.parametrize("knobs", [{}, {"gemm_persist": 0}, {"gemm_persist": 0, "gemm_lean": 0}, {"gemm_big": 1}],
+                         ids=["default_persistent_grid", "one_tile_per_workgroup", "generic_epilogue", "four_wave_kernel"])
 @pytest.mark.parametrize("epi_name,shape,seq", [("store", (512, 1024, 256), 0), ("store", (10240, 1024, 128), 0), ("store", (10300, 2048, 192), 0),
                                                 ("gate", (768, 512, 128), 0), ("gate", (10240, 1024, 256), 0), ("gate", (10301, 1024, 128), 0),
                                                 ("rope", (1024, 768, 128), 256), ("rope", (4096, 3072, 128), 1024), ("rope", (4120, 3072, 128), 1030)])
@@ -110,7 +111,7 @@ def test_linear_fused_epilogues(knobs, epi_name, shape, seq):
         out = G.op_linear_fused(1, epi, A, W, b, act, gate, rowmask, rope, heads, seq)
     finally:
         for k in knobs:
-            _lib.check(lib.f5_tuning_set(k.encode(), {"gemm_lean": 1, "gemm_big": 0}[k]))
+            _lib.check(lib.f5_tuning_set(k.encode(), {"gemm_lean": 1, "gemm_big": 0, "gemm_persist": 1}[k]))
     base = G.op_linear_fused(0, epi, A, W, b, act, gate, rowmask, rope, heads, seq)
     assert rel_l2(base, ref) < 3e-3   # bf16 output rounding: 2^-9 relative per element
     assert rel_l2(out, ref) < 3e-3
