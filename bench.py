@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 BASE_ARCH = dict(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, text_mask_padding=False, conv_layers=4, pe_attn_head=1)
 VOCAB = 2545
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
-QKV_TRAFFIC_BYTES = int((303430.1875 * 2 + 401031.1875) * 1024)  # profiles/r1_04_c2_l2_patch_order_kernel_stats.md (PMC passes)
+QKV_TRAFFIC_BYTES = int((320754.9 * 2 + 393299.5) * 1024)  # profiles/r1_08_c2_persistent_grid_kernel_stats.md (PMC passes)
 
 
 def synth_weights(model, seed=0):
