@@ -23,8 +23,9 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& s, int base) {
 
 // ABL: timing-only ablations (wrong results): 1 = no softmax math (P = S), 2 = no K/V tile refresh (tile 0 reused, no loads/stores/barriers),
 // 3 = no PV MFMAs, 4 = no QK^T MFMAs
-template <bool MASKED, int ABL>
-__global__ __launch_bounds__(256, 2) void attn_fast_kernel(const bf16_t* __restrict__ qkv, int ldq, int inner, const uint8_t* __restrict__ mask,
+// OCC: waves per SIMD the register allocation must allow (3: 152 VGPRs as the compiler likes it; 4: capped at 128, a few spills)
+template <bool MASKED, int ABL, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const bf16_t* __restrict__ qkv, int ldq, int inner, const uint8_t* __restrict__ mask,
                                                            bf16_t* __restrict__ out, int ldo, int N, float c /* scale * log2(e) */) {
     constexpr int KT = 64;                 // keys per tile
     constexpr int TILE_BYTES = KT * 128;   // 64 keys x 64 dims x 2 B
@@ -430,6 +431,7 @@ __global__ __launch_bounds__(256, 2) void attn_fast2_kernel(const bf16_t* __rest
     }
 }
 
+int g_attn_occ = 0;      // tuning knob ("attn_occ"): 4 = build of the 32-query kernel capped at 128 VGPRs (4 waves per SIMD)
 int g_attn_variant = 0;  // tuning knob ("attn_variant"): 0 = by sequence length, 1 = 32 queries per wave (128 per workgroup), 2 = 64 queries per wave
 int g_attn_ablate = 0;  // tuning knob ("attn_ablate"): timing-only ablations of the unmasked kernel
 
@@ -450,7 +452,12 @@ int launch_attention_fast(int B, int N, int H, const void* qkv, int ldq, const u
         return 0;
     }
     dim3 grid(cdiv(N, 128), H, B), block(256);
-    if (masked)
+    if (g_attn_occ == 4 && g_attn_ablate == 0) {
+        if (masked)
+            hipLaunchKernelGGL((attn_fast_kernel<true, 0, 4>), grid, block, 0, stream, (const bf16_t*)qkv, ldq, H * 64, mask, (bf16_t*)out, ldo, N, c);
+        else
+            hipLaunchKernelGGL((attn_fast_kernel<false, 0, 4>), grid, block, 0, stream, (const bf16_t*)qkv, ldq, H * 64, mask, (bf16_t*)out, ldo, N, c);
+    } else if (masked)
         hipLaunchKernelGGL((attn_fast_kernel<true, 0>), grid, block, 0, stream, (const bf16_t*)qkv, ldq, H * 64, mask, (bf16_t*)out, ldo, N, c);
     else if (g_attn_ablate == 1)
         hipLaunchKernelGGL((attn_fast_kernel<false, 1>), grid, block, 0, stream, (const bf16_t*)qkv, ldq, H * 64, mask, (bf16_t*)out, ldo, N, c);
