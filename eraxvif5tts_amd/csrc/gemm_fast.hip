@@ -4,9 +4,15 @@
 //   * 256-token x BN-feature output tile per 512-thread workgroup (8 wavefronts, one workgroup per CU, 2 waves per SIMD),
 //     v_mfma_f32_16x16x32_bf16 with the weight rows on the MFMA row index, so each lane finishes with 4
 //     consecutive output features of one token (vector stores, lane-local RoPE pairs);
-//   * both operand tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (LDS-DMA, no VGPR staging) through a 4-slot ring of
-//     32-deep K-steps: three K-steps are in flight while one is consumed (counted s_waitcnt vmcnt, never 0 in the loop),
-//     one raw s_barrier per K-step;
+//   * both operand tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (LDS-DMA, no VGPR staging) through a ring of 32-deep
+//     K-steps (5 slots = the whole 160 KiB LDS for the 256-wide tile): four K-steps are in flight while one is consumed
+//     (counted s_waitcnt vmcnt, never 0 in the loop), raw s_barriers;
+//   * schedules (template VAR): 1 = the two waves of a SIMD staggered by one barrier interval (one feeds the matrix pipe while
+//     the other issues DMA and reads fragments); 30 = the same on a PERSISTENT grid (one workgroup per CU walks tiles, the DMA
+//     front crosses into the next tile under the epilogue) -- the production schedule for whole-tile block linears;
+//     0 = plain ring (narrow tiles); 2 / 3 / 20 and 10..17, 31, 32 = measured alternatives and timing-only ablations;
+//   * every accumulator starts from its feature's bias (identical fp32 sums in every variant and tile width); whole tiles take
+//     the lean store-only epilogue, ragged tiles the generic one;
 //   * LDS image is lane-linear (a DMA instruction writes 16 rows x 64 B); bank conflicts of the ds_read_b128 fragment
 //     reads are removed by an XOR swizzle applied on the *source* address and on the read (16-byte chunk ^= (-(row>>2))&3);
 //   * blockIdx -> tile mapping is XCD-aware (each XCD's L2 sees a contiguous band of token tiles x all feature tiles);
