@@ -48,6 +48,7 @@ struct GemmParams {
     int conv_cg, conv_win;
     int tile_group;  // tuned kernel: token tiles per L2 patch (set by the launcher)
     int nt_store;    // tuned kernel, lean epilogue: non-temporal stores (set by the launcher)
+    int skew_ticks;  // persistent tuned kernel, experiment: every other workgroup starts this many 100 MHz ticks late (de-synchronises the store bursts)
     int ablate;      // gemm_big.hip timing ablations (bit 0: no MFMA, 1: no DMA refill, 2: no fragment reads, 3: no epilogue)
     int lean_epi;    // tuned kernel: whole tiles take the lean epilogue (set by the launcher; 0 = always the generic one)
 };

@@ -322,7 +322,7 @@ extern int g_gemm_group;
 
 int launch_gemm_big(const GemmParams& p0, int epi, hipStream_t stream) {
     GemmParams p = p0;
-    p.tile_group = g_gemm_group;
+    p.tile_group = g_gemm_group > 0 ? g_gemm_group : 8;
     p.ablate = g_gemm_big_ablate;
     const int tiles_m = cdiv(p.M, 256), tiles_n = p.N / 256;
     const int nblocks = tiles_m * tiles_n;

@@ -53,6 +53,7 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
         tm0 = tile_m * BM;
         tn0 = tile_n * BN;
     };
+    constexpr bool P30 = VAR == 30 || VAR == 33;  // production persistent schedule (33: timing-only, without the epilogue's stores)
     constexpr bool PERSIST = VAR >= 30;  // (31 / 32: timing-only ablations without the epilogue's stores / without the epilogue)  // persistent grid: a block walks tiles bid, bid + gridDim.x, ... and prefetches across tile boundaries
     int m0, n0;                          // tile being computed (epilogue side)
     tile_mn(blockIdx.x, m0, n0);
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
             const int n = n0 + wn * WN + i * 16 + 4 * fq;
             okn[i] = n + 3 < p.N;  // N % 4 == 0: a lane's 4 features are valid together
             ncol[i] = okn[i] ? n : 0;
-            if constexpr (VAR != 30) bias4[i] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ncol[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (!P30) bias4[i] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ncol[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (EPI == EPI_GATE_T || EPI == EPI_RESID)
                 gate4[i] = (p.gate && p.gate_bstride == 0) ? *reinterpret_cast<const f32x4*>(p.gate + ncol[i]) : f32x4{1.f, 1.f, 1.f, 1.f};
         }
@@ -448,8 +449,14 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
                 q1 = keep ? q1 : u32x4{0u, 0u, 0u, 0u};
             }
             bf16_t* o = orow + j * jstride;
-            if constexpr (VAR == 16) {  // timing-only: the lean epilogue without its stores
+            if constexpr (VAR == 16 || VAR == 33) {  // timing-only: the lean epilogue without its stores
                 asm volatile("" ::"v"(q0), "v"(q1), "v"(o));
+            } else if (p.nt_store == 2) {  // experiment: write-through, system-scope stores (sc0 sc1): the lines do not stay dirty in L2
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(o), "v"(q0) : "memory");
+                asm volatile("global_store_dwordx4 %0, %1, off offset:64 sc0 sc1" ::"v"(o), "v"(q1) : "memory");
+            } else if (p.nt_store == 3) {  // experiment: sc0 sc1 nt
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(o), "v"(q0) : "memory");
+                asm volatile("global_store_dwordx4 %0, %1, off offset:64 sc0 sc1 nt" ::"v"(o), "v"(q1) : "memory");
             } else if (VAR == 17 || p.nt_store) {  // streaming stores: the output tile does not displace the operand slices in L2
                 __builtin_nontemporal_store(q0, reinterpret_cast<u32x4*>(o));
                 __builtin_nontemporal_store(q1, reinterpret_cast<u32x4*>(o + 32));
@@ -468,7 +475,7 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
         return ok;
     };
     auto epilogue = [&]() {
-        if constexpr (VAR == 30) {  // the launcher guarantees whole tiles and lean operand forms: no generic code in this build
+        if constexpr (P30) {  // the launcher guarantees whole tiles and lean operand forms: no generic code in this build
             if (p.act == ACT_GELU_TANH)
                 lean_epilogue(std::integral_constant<int, ACT_GELU_TANH>{});
             else
@@ -489,6 +496,10 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
     };
 
     if constexpr (PERSIST) {
+        if (p.skew_ticks > 0 && ((blockIdx.x >> 3) & 1)) {  // experiment: half of the workgroups of every XCD start late
+            const unsigned long long t0 = wall_clock64();
+            while (wall_clock64() - t0 < (unsigned long long)p.skew_ticks) __builtin_amdgcn_s_sleep(32);
+        }
         // ---- persistent staggered ring: the ring never drains between tiles.  Global stage g = (tile ordinal) * nk + kt lives in
         //      slot g % NSTAGE; the DMA front runs D stages ahead and crosses into the next tile's operands, so a tile's first
         //      K-steps are already in LDS when the previous tile's epilogue ends.  The two wave groups re-synchronise around
@@ -526,11 +537,11 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
                 for (int j = 0; j < MI; ++j) acc[i][j] = b4[i];
         };
         [[maybe_unused]] f32x4 b0[NI];
-        if constexpr (VAR == 30) load_bias(n0, b0);
+        if constexpr (P30) load_bias(n0, b0);
 #pragma unroll
         for (int d = 0; d < D; ++d)
             if (gi < total) issue_next();
-        if constexpr (VAR == 30)
+        if constexpr (P30)
             acc_from(b0);
         else
             init_acc();
@@ -539,24 +550,27 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
         const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
         int g = 0, slot_c = 0;
         bf16x8 wf[NI], af[MI];
-        int nm0 = 0, nn0 = 0;
+        int nm0 = m0, nn0 = n0;
         for (int t = 0; t < my_tiles; ++t) {
             if (t > 0) {
-                if constexpr (VAR == 30) {
+                if constexpr (P30) {
                     m0 = nm0;
                     n0 = nn0;
                 } else {
                     tile_mn(blockIdx.x + t * G, m0, n0);
                 }
                 prep_epilogue();
-                if constexpr (VAR != 30) init_acc();
+                if constexpr (!P30) init_acc();
             }
             if (late) __builtin_amdgcn_s_barrier();
             for (int kt = 0; kt < nk; ++kt) {
                 if (gi < total) issue_next();
                 read_frags(slot_c, wf, af);
-                // my pieces of global stage g+1 must have landed before the barrier that precedes anybody's next P phase
-                wait_pieces(g + 1 < total ? (gi - 1) - (g + 1) : 0);
+                // my pieces of global stage g+1 must have landed before the barrier that precedes anybody's next P phase.
+                // P30, first three K-steps of a tile after the first: the four stages fetched ahead landed BEFORE the previous epilogue
+                // (explicit vmcnt(0) there), so no wait is needed -- and none may be issued: vmcnt retires in order and the epilogue's
+                // stores sit in front of the DMA issued since, a wait here would hold the wave until all its stores are acknowledged.
+                if (!(P30 && t > 0 && kt < 3)) wait_pieces(g + 1 < total ? (gi - 1) - (g + 1) : 0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -568,17 +582,23 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
                 ++g;
                 slot_c = slot_c + 1 == NSTAGE ? 0 : slot_c + 1;
             }
-            if (!late) __builtin_amdgcn_s_barrier();  // same barrier count for both groups; both now store together
-            if constexpr (VAR == 30) {
+            if constexpr (P30) {
+                // Next tile's bias (after the last tile: the same tile's again, unused) -- unconditional code on purpose: with the
+                // loads, their use and the accumulator restart under `if (more tiles)`, the compiler's vmcnt bookkeeping merged the two
+                // paths into a vmcnt(0) BEHIND the epilogue's stores (loads and stores share the counter on this ISA), i.e. every tile
+                // waited for its own 128 KiB of stores to be acknowledged before the next main loop could start.
                 f32x4 bn[NI];
-                const bool more = t + 1 < my_tiles;
-                if (more) {
-                    tile_mn(blockIdx.x + (t + 1) * G, nm0, nn0);
-                    load_bias(nn0, bn);
-                }
+                if (t + 1 < my_tiles) tile_mn(blockIdx.x + (t + 1) * G, nm0, nn0);
+                load_bias(nn0, bn);  // in flight across the re-synchronising barrier
+                if (!late) __builtin_amdgcn_s_barrier();  // same barrier count for both groups; both now store together
+#pragma unroll
+                for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(bn[i]));  // the wait for the bias sits here: only loads are in flight
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and every K-step fetched ahead has landed (see the main loop)
+                __builtin_amdgcn_sched_barrier(0);
                 epilogue();
-                if (more) acc_from(bn);
+                acc_from(bn);
             } else {
+                if (!late) __builtin_amdgcn_s_barrier();
                 epilogue();
             }
         }
@@ -694,8 +714,9 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
 }
 
 int g_gemm_variant = 1;  // tuning knob (f5_tuning_set("gemm_variant", v)): 0 = plain ring, 1 = ring + staggered wave groups, 10-12 ablations
-int g_gemm_group = 8;    // tuning knob ("gemm_group"): token tiles per L2 patch (1 = feature-tile-fastest order)
+int g_gemm_group = 0;    // tuning knob ("gemm_group"): token tiles per L2 patch (0 = by shape, 1 = feature-tile-fastest order)
 int g_gemm_persist_grid = 0;  // tuning knob ("gemm_persist_grid"): workgroups of the persistent kernel (0 = one per CU of the device)
+int g_gemm_skew = 0;          // tuning knob ("gemm_skew"): see GemmParams::skew_ticks
 int g_gemm_persist = 1;       // tuning knob ("gemm_persist"): 1 = whole-tile block linears run on the persistent grid
 static int persist_grid() {
     if (g_gemm_persist_grid > 0) return g_gemm_persist_grid;
@@ -714,9 +735,11 @@ int g_gemm_stages = 5;   // tuning knob ("gemm_stages"): LDS ring slots of the 2
 
 template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmParams& p0, hipStream_t stream) {
     GemmParams p = p0;
-    p.tile_group = g_gemm_group;
+    // L2 patch height: 8 token tiles per XCD patch; 16 for the 8-feature-tile (N = 2048) projection (tools/group_probe.py: FF1 985 -> 1 020 TFLOP/s)
+    p.tile_group = g_gemm_group > 0 ? g_gemm_group : (cdiv(p.N, BN) == 8 ? 16 : 8);
     p.lean_epi = g_gemm_lean;
-    p.nt_store = (g_gemm_nt >> EPI) & 1;
+    p.skew_ticks = g_gemm_skew;
+    p.nt_store = g_gemm_nt >= 256 ? (g_gemm_nt >> 8) : ((g_gemm_nt >> EPI) & 1);  // >= 256: store flavour experiment (2 = sc0 sc1, 3 = sc0 sc1 nt) for every epilogue
     const int tiles_m = cdiv(p.M, 256), tiles_n = cdiv(p.N, BN);
     const int nblocks = tiles_m * tiles_n;
     dim3 grid(nblocks), block(512);
@@ -745,10 +768,11 @@ template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmPa
             hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 3, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
         else if (g_gemm_variant == 2 && MODE == GEMM_DENSE && p.K % 64 == 0 && p.K >= 128)
             hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI, 2, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
-        else if ((g_gemm_variant == 31 || g_gemm_variant == 32) && MODE == GEMM_DENSE && EPI == EPI_GATE_T) {
-            const dim3 pg(nblocks < g_gemm_persist_grid ? nblocks : g_gemm_persist_grid);
+        else if ((g_gemm_variant >= 31 && g_gemm_variant <= 33) && MODE == GEMM_DENSE && EPI == EPI_GATE_T) {
+            const dim3 pg(nblocks < persist_grid() ? nblocks : persist_grid());
             if (g_gemm_variant == 31) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI_GATE_T, 31, 5>), pg, block, 0, stream, p, tiles_n, nblocks);
             if (g_gemm_variant == 32) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI_GATE_T, 32, 5>), pg, block, 0, stream, p, tiles_n, nblocks);
+            if (g_gemm_variant == 33) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI_GATE_T, 33, 5>), pg, block, 0, stream, p, tiles_n, nblocks);
         } else if ((g_gemm_variant == 30 || (g_gemm_variant == 1 && g_gemm_persist)) && persist_ok)
             hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI, 30, 5>), dim3(nblocks < persist_grid() ? nblocks : persist_grid()), block, 0,
                                stream, p, tiles_n, nblocks);

@@ -283,7 +283,7 @@ extern "C" int f5_bench_attention(int kernel, int B, int N, int H, int iters, fl
     return sync_and_release(a, st, rc);
 }
 
-extern int g_gemm_variant, g_gemm_stages, g_gemm_group, g_gemm_persist_grid, g_gemm_persist, g_gemm_lean, g_gemm_nt, g_gemm_big, g_gemm_big_ablate, g_ln_defer, g_conv31, g_attn_occ, g_attn_ablate, g_attn_variant;
+extern int g_gemm_variant, g_gemm_stages, g_gemm_group, g_gemm_persist_grid, g_gemm_persist, g_gemm_skew, g_gemm_lean, g_gemm_nt, g_gemm_big, g_gemm_big_ablate, g_ln_defer, g_conv31, g_attn_occ, g_attn_ablate, g_attn_variant;
 extern "C" int f5_tuning_set(const char* key, int value) {
     if (!key) return f5_fail(F5_EINVAL, "null key");
     if (strcmp(key, "gemm_variant") == 0) {
@@ -332,6 +332,10 @@ extern "C" int f5_tuning_set(const char* key, int value) {
     }
     if (strcmp(key, "gemm_lean") == 0) {
         g_gemm_lean = value != 0;
+        return 0;
+    }
+    if (strcmp(key, "gemm_skew") == 0) {
+        g_gemm_skew = value;
         return 0;
     }
     if (strcmp(key, "gemm_persist") == 0) {
