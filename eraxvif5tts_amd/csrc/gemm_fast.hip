@@ -760,26 +760,22 @@ template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmPa
             if (g_gemm_variant == 15) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 15, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
             if (g_gemm_variant == 16) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 16, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
             if (g_gemm_variant == 17) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 17, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
-        } else if (g_gemm_variant == 20 && MODE == GEMM_DENSE && p.K % 64 == 0)
-            hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI, 20, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
-        else if (g_gemm_variant == 21 && MODE == GEMM_DENSE && EPI == EPI_GATE_T && p.K % 64 == 0)
-            hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI_GATE_T, 21, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
-        else if (g_gemm_variant == 3)
-            hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 3, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
-        else if (g_gemm_variant == 2 && MODE == GEMM_DENSE && p.K % 64 == 0 && p.K >= 128)
-            hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI, 2, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
+        }
+        // (schedules 3 = split DMA issue and 20/21 = half-slab ring with whole-line pieces are kept in the kernel source as measured
+        //  alternatives but no longer instantiated: -4 % / 0 %)
+        else if (g_gemm_variant == 2 && MODE == GEMM_DENSE && EPI == EPI_GATE_T && p.K % 64 == 0 && p.K >= 128)  // paired K-step DMA (-3 %)
+            hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI_GATE_T, 2, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
         else if ((g_gemm_variant >= 31 && g_gemm_variant <= 33) && MODE == GEMM_DENSE && EPI == EPI_GATE_T) {
             const dim3 pg(nblocks < persist_grid() ? nblocks : persist_grid());
             if (g_gemm_variant == 31) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI_GATE_T, 31, 5>), pg, block, 0, stream, p, tiles_n, nblocks);
             if (g_gemm_variant == 32) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI_GATE_T, 32, 5>), pg, block, 0, stream, p, tiles_n, nblocks);
             if (g_gemm_variant == 33) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI_GATE_T, 33, 5>), pg, block, 0, stream, p, tiles_n, nblocks);
-        } else if ((g_gemm_variant == 30 || (g_gemm_variant == 1 && g_gemm_persist)) && persist_ok)
-            hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI, 30, 5>), dim3(nblocks < persist_grid() ? nblocks : persist_grid()), block, 0,
-                               stream, p, tiles_n, nblocks);
-        else if (g_gemm_stages == 5)
+        } else if ((g_gemm_variant == 30 || (g_gemm_variant == 1 && g_gemm_persist)) && persist_ok) {
+            if constexpr (EPI == EPI_STORE_T || EPI == EPI_GATE_T || EPI == EPI_ROPE_T)
+                hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI, 30, 5>), dim3(nblocks < persist_grid() ? nblocks : persist_grid()), block,
+                                   0, stream, p, tiles_n, nblocks);
+        } else
             hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 1, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
-        else
-            hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 1, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
     } else {
         hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 0, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
     }
