@@ -10,7 +10,10 @@
 // YMODE: 0 = x only; 1 = x += y, written back; 2 = (x + y) normalised but x NOT written back (the add is repeated by the next pass);
 //        3 = x = (x + y) + y2, written back.  Modes 2 + 3 alternate inside a DiT block: the fp32 residual stream is written once per
 //        block instead of twice, with bit-identical sums (same operands, same order).
-template <typename TO, int MAXV, int YMODE>
+// FULL: dim == MAXV * 256 (every lane owns MAXV whole vectors): no per-vector bounds branch, so ALL loads of a row (x, y, y2 and the
+// modulation vectors) are issued before the first use -- with the branches the compiler emitted one dependent memory round trip
+// per vector column (4 per row and pass).
+template <typename TO, int MAXV, int YMODE, bool FULL>
 __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, int ldx, int rows, int dim, const TO* __restrict__ y, int ldy,
                                                         const TO* __restrict__ y2, const float* __restrict__ mul, const float* __restrict__ add,
                                                         int mod_bstride, int rows_per_batch, float add_one, TO* __restrict__ out, int ldo) {
@@ -19,24 +22,42 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, i
     if (row >= rows) return;
     float* xr = x + (size_t)row * ldx;
     const int nvec = dim >> 2;  // dim % 4 == 0
-    f32x4 v[MAXV];
-    float s = 0.f;
-    auto load_y = [&](const TO* yr) {
-        if constexpr (sizeof(TO) == 2) {
-            const bf16x4 y4 = *reinterpret_cast<const bf16x4*>(yr);
-            return f32x4{(float)y4[0], (float)y4[1], (float)y4[2], (float)y4[3]};
-        } else {
-            return *reinterpret_cast<const f32x4*>(yr);
-        }
+    typedef typename std::conditional<sizeof(TO) == 2, bf16x4, f32x4>::type yvec_t;
+    auto widen = [](const yvec_t& r) {
+        if constexpr (sizeof(TO) == 2)
+            return f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+        else
+            return r;
     };
+    const size_t moff = (size_t)(row / rows_per_batch) * mod_bstride;
+    f32x4 v[MAXV], m4[MAXV], a4[MAXV];
+    [[maybe_unused]] yvec_t yr[MAXV], yr2[MAXV];
+    // ---- every load of the row first
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + i * 64;
-        if (c < nvec) {
+        if (FULL || c < nvec) {
             v[i] = *reinterpret_cast<const f32x4*>(xr + c * 4);
+            if constexpr (YMODE != 0) yr[i] = *reinterpret_cast<const yvec_t*>(y + (size_t)row * ldy + c * 4);
+            if constexpr (YMODE == 3) yr2[i] = *reinterpret_cast<const yvec_t*>(y2 + (size_t)row * ldy + c * 4);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (FULL || c < nvec) {
+            m4[i] = *reinterpret_cast<const f32x4*>(mul + moff + c * 4);
+            a4[i] = *reinterpret_cast<const f32x4*>(add + moff + c * 4);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (FULL || c < nvec) {
             if constexpr (YMODE != 0) {
-                v[i] += load_y(y + (size_t)row * ldy + c * 4);
-                if constexpr (YMODE == 3) v[i] += load_y(y2 + (size_t)row * ldy + c * 4);
+                v[i] += widen(yr[i]);
+                if constexpr (YMODE == 3) v[i] += widen(yr2[i]);
                 if constexpr (YMODE != 2) *reinterpret_cast<f32x4*>(xr + c * 4) = v[i];
             }
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
@@ -47,7 +68,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, i
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + i * 64;
-        if (c < nvec) {
+        if (FULL || c < nvec) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float d = v[i][e] - mean;
@@ -56,17 +77,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, i
         }
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)dim + 1e-6f);
-    const size_t moff = (size_t)(row / rows_per_batch) * mod_bstride;
     TO* orow = out + (size_t)row * ldo;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + i * 64;
-        if (c < nvec) {
-            const f32x4 m4 = *reinterpret_cast<const f32x4*>(mul + moff + c * 4);
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(add + moff + c * 4);
+        if (FULL || c < nvec) {
             float o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * (add_one + m4[e]) + a4[e];
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * (add_one + m4[i][e]) + a4[i][e];
             if constexpr (sizeof(TO) == 2) {
                 *reinterpret_cast<bf16x4*>(orow + c * 4) = bf16x4{(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
             } else {
@@ -80,9 +98,15 @@ template <typename TO, int MAXV>
 static void ln_launch(float* x, int ldx, int rows, int dim, const void* y, int ldy, const void* y2, int ymode, const float* mul, const float* add,
                       int mod_bstride, int rows_per_batch, float one, void* out, int ldo, hipStream_t stream) {
     dim3 grid(cdiv(rows, 4)), block(256);
-#define F5_LN_CASE(M)                                                                                                                  \
-    hipLaunchKernelGGL((layernorm_kernel<TO, MAXV, M>), grid, block, 0, stream, x, ldx, rows, dim, (const TO*)y, ldy, (const TO*)y2, mul, add, \
-                       mod_bstride, rows_per_batch, one, (TO*)out, ldo)
+#define F5_LN_CASE(M)                                                                                                                        \
+    do {                                                                                                                                     \
+        if (dim == MAXV * 256)                                                                                                               \
+            hipLaunchKernelGGL((layernorm_kernel<TO, MAXV, M, true>), grid, block, 0, stream, x, ldx, rows, dim, (const TO*)y, ldy, (const TO*)y2, \
+                               mul, add, mod_bstride, rows_per_batch, one, (TO*)out, ldo);                                                   \
+        else                                                                                                                                 \
+            hipLaunchKernelGGL((layernorm_kernel<TO, MAXV, M, false>), grid, block, 0, stream, x, ldx, rows, dim, (const TO*)y, ldy, (const TO*)y2, \
+                               mul, add, mod_bstride, rows_per_batch, one, (TO*)out, ldo);                                                   \
+    } while (0)
     if (ymode == 0) F5_LN_CASE(0);
     else if (ymode == 1) F5_LN_CASE(1);
     else if (ymode == 2) F5_LN_CASE(2);
