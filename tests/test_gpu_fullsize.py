@@ -117,3 +117,33 @@ def test_true_depth_bf16_sampler_stays_within_tolerance_of_fp32_mode():
     err = rel_l2(gen(outs["bf16"]), gen(outs["fp32"]))
     print(f"bf16 vs fp32 mode, 22 blocks x 32 steps: rel-L2 {err:.3e}")
     assert torch.isfinite(outs["bf16"]).all() and err < 2e-2
+
+
+def test_true_depth_ragged_shapes_match_fp32_mode():
+    """F5TTS_Base at shapes where nothing is a tile multiple (3 utterances x 777 frames: 4 662 token rows, key tail of 9, unequal
+    durations): ragged GEMM tiles (generic epilogue, clamped operand rows), the ragged last tile of the halo-tile conv kernel, the
+    masked attention tail -- bf16 production path against the exact-fp32 mode of the same library, NFE = 8."""
+    import bench
+    from eraxvif5tts_amd.model import CFM, DiT
+    B, N = 3, 777
+    cond, text, lens, dur = bench.synth_batch(B, N, "cuda", seed=21)
+    dur[1], dur[2] = 700, 601
+    g = torch.Generator().manual_seed(22)
+    y0 = torch.randn(B, N, 100, generator=g)
+    y0 = y0 * (torch.arange(N)[None, :, None] < dur.cpu()[:, None, None])
+    outs = {}
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(4321)
+        model = bench.synth_weights(DiT(**bench.BASE_ARCH, text_num_embeds=bench.VOCAB, mel_dim=100, precision=prec), seed=0)
+        cfm = CFM(transformer=model, mel_spec_kwargs={"mel_spec_type": "vocos"}).cuda()
+        out, _ = cfm.sample(cond=cond, text=text, duration=dur, lens=lens, steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, y0=y0,
+                            return_trajectory=False)
+        outs[prec] = out.cpu()
+        del cfm, model
+        torch.cuda.empty_cache()
+    n_ref = cond.shape[1]
+    gen = lambda t: torch.cat([t[b, n_ref:int(dur[b])] for b in range(B)])
+    err = rel_l2(gen(outs["bf16"]), gen(outs["fp32"]))
+    print(f"ragged shapes, bf16 vs fp32 mode, 22 blocks x 8 steps: rel-L2 {err:.3e}")
+    assert torch.isfinite(outs["bf16"]).all() and err < 2e-2
+    assert torch.equal(outs["bf16"][:, :n_ref], cond.cpu())
