@@ -184,13 +184,21 @@ def main():
         iso_ok = lib.f5_bench_gemm_site(1, 0, rows, N, 1024, 16, 2048, 10, C.byref(iso), _lib.stream_ptr()) == 0
         result["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
-                              # HBM-side bytes per launch from the rocprofv3 PMC passes recorded in profiles/r1_04_* (FETCH_SIZE x 2 on gfx950
+                              # HBM-side bytes per launch from the rocprofv3 PMC passes recorded in profiles/r1_08_* (FETCH_SIZE x 2 on gfx950
                               # + WRITE_SIZE); only meaningful for the default C2 shape, null otherwise
                               "traffic": QKV_TRAFFIC_BYTES if (rows == 65536 and N == 1024) else None,
-                              "kernel": "gemm_fast_kernel<256,128,DENSE,QKV+RoPE epilogue>",
+                              "kernel": "gemm_fast_kernel<256,128,DENSE,QKV+RoPE epilogue,persistent grid>",
                               "launch": f"M={rows} N=3072 K=1024, {flops / 1e9:.1f} GFLOP, {ms.value:.4f} ms mean over {cnt.value} launches inside an "
                                         f"eager sample() (HIP event pairs on the launch stream)",
                               "isolated_tflops": round(flops / (iso.value * 1e-3) / 1e12, 2) if iso_ok else None}
+        # what the matrix pipe itself sustains on THIS device (register-resident MFMA stream, no memory traffic): clock-limited with
+        # zero operands, power-limited with realistic ones -- context for `frac`, whose denominator stays the data-sheet peak
+        sus = {}
+        for label, rnd in (("zero_operands", 0), ("random_operands", 1)):
+            tf = C.c_float(0.0)
+            if lib.f5_bench_mfma_rate(rnd, C.byref(tf), _lib.stream_ptr()) == 0:
+                sus[label] = round(tf.value, 1)
+        result["roofline"]["mfma_sustained_tflops"] = sus or None
         # whole-loop MFMA fraction from the algorithmic FLOPs of SURVEY.md 8(d)
         per_token = 378.9e6 + 90112.0 * N
         total_flops = per_token * B * N * (2 if args.cfg >= 1e-5 else 1) * nfe * args.steps * world

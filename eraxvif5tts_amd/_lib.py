@@ -60,6 +60,7 @@ _PROTOS = {
     "f5_op_conv_pos_embed": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "f5_bench_gemm_site": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float), _P]),
     "f5_bench_attention": (_I, [_I, _I, _I, _I, _I, C.POINTER(C.c_float), _P]),
+    "f5_bench_mfma_rate": (_I, [_I, C.POINTER(C.c_float), _P]),
     "f5_tuning_set": (_I, [C.c_char_p, _I]),
     "f5_vocoder_create": (_I, [C.POINTER(VocosConfig), C.POINTER(_P)]),
     "f5_vocoder_set_tensor": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I]),

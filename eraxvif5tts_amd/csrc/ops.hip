@@ -283,6 +283,74 @@ extern "C" int f5_bench_attention(int kernel, int B, int N, int H, int iters, fl
     return sync_and_release(a, st, rc);
 }
 
+// ----------------------------------------------------------------------------- what the matrix pipe sustains on this device
+// Register-resident v_mfma_f32_16x16x32_bf16 stream: 4 waves per workgroup (one per SIMD), 64 independent accumulator tiles per
+// wave, no memory traffic.  With zero operands the part holds its clock; with realistic (pseudo-random) operands the MFMA rate is
+// power-limited -- that second number, not the data-sheet peak, is what a dense bf16 GEMM can approach here.
+__global__ __launch_bounds__(256, 1) void mfma_rate_kernel(int iters, int random_operands, float* sink) {
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 w[8], a[8];
+    unsigned h = (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            h = h * 1664525u + 1013904223u;
+            w[i][e] = random_operands ? (bf16_t)(((int)(h >> 20) & 0xfff) * (1.0f / 1024.0f) - 2.0f) : (bf16_t)0.f;
+            h = h * 1664525u + 1013904223u;
+            a[i][e] = random_operands ? (bf16_t)(((int)(h >> 20) & 0xfff) * (1.0f / 32768.0f) - 0.0625f) : (bf16_t)0.f;
+        }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(w[i]), "v"(a[j]));
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += acc[i][j][0];
+    if (s == 12345.678f) sink[0] = s;  // keeps the accumulators alive
+}
+
+extern "C" int f5_bench_mfma_rate(int random_operands, float* tflops, f5_stream_t stream) {
+    F5_TRY(f5_check_device());
+    if (!tflops) return f5_fail(F5_EINVAL, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    int dev = 0, cus = 0;
+    F5_HIP(hipGetDevice(&dev));
+    F5_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int iters = 2000, blocks = cus * 4;  // 4 workgroups per CU back to back: ~1.5 ms per launch
+    DevArena a;
+    float* sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = 0;
+    do {
+        if ((rc = a.alloc_t(&sink, 16))) break;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { rc = f5_fail(F5_EHIP, "hipEventCreate failed"); break; }
+        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(mfma_rate_kernel, dim3(blocks), dim3(256), 0, st, iters, random_operands, sink);  // clocks settle
+        (void)hipEventRecord(e0, st);
+        const int reps = 10;
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(mfma_rate_kernel, dim3(blocks), dim3(256), 0, st, iters, random_operands, sink);
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) { rc = f5_fail(F5_EHIP, "event sync failed"); break; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        const double flops = (double)reps * blocks * 4.0 * iters * 64.0 * (2.0 * 16 * 16 * 32);
+        *tflops = (float)(flops / (ms * 1e-3) / 1e12);
+    } while (0);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return sync_and_release(a, st, rc);
+}
+
 extern int g_gemm_variant, g_gemm_stages, g_gemm_group, g_gemm_persist_grid, g_gemm_persist, g_gemm_skew, g_gemm_lean, g_gemm_nt, g_gemm_big, g_gemm_big_ablate, g_ln_defer, g_conv31, g_attn_occ, g_attn_ablate, g_attn_variant;
 extern "C" int f5_tuning_set(const char* key, int value) {
     if (!key) return f5_fail(F5_EINVAL, "null key");

@@ -179,6 +179,9 @@ int f5_op_conv_pos_embed(int precision, int B, int N, int dim, const float* x, c
 int f5_bench_gemm_site(int kernel, int site, int rows, int seq, int dim, int heads, int ff_inner, int iters, float* ms_avg,
                        f5_stream_t stream);
 int f5_bench_attention(int kernel, int B, int N, int H, int iters, float* ms_avg, f5_stream_t stream);
+/* Sustained rate of a register-resident v_mfma_f32_16x16x32_bf16 stream on every CU (no memory traffic): random_operands = 0 zeros
+ * (clock-limited), 1 pseudo-random bf16 values (power-limited: what a dense bf16 GEMM can approach on this device). */
+int f5_bench_mfma_rate(int random_operands, float* tflops, f5_stream_t stream);
 /* process-wide kernel tuning knobs for A/B measurements ("gemm_variant": main-loop schedule of the tuned GEMM) */
 int f5_tuning_set(const char* key, int value);
 

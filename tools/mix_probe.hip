@@ -21,8 +21,10 @@ template <int N, int I = 0, typename F> __device__ __forceinline__ void static_f
 }
 
 // 4 waves: per step per wave 64 MFMA, 8 DMA (as 4 adjacent pairs... 16 per two steps), 16 ds_read
+__device__ int g_random_frags = 0;  // 1: fragment registers start from pseudo-random bf16 values in [-2, 2) instead of zeros (data-dependent power)
+
 template <bool MFMA, bool DMA, bool RD, bool BAR, int RDPOS, int DMAMODE = 0>
-__global__ __launch_bounds__(256, 1) void mix4(const char* A, const char* W, int ld_b, int nk, float* sink) {
+__global__ __launch_bounds__(256, 1) void mix4(const char* A, const char* W, int ld_b, int nk, float* sink, int random_frags) {
     __shared__ __attribute__((aligned(16))) char smem[5 * 32768];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bid = blockIdx.x, swz = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
@@ -41,7 +43,20 @@ __global__ __launch_bounds__(256, 1) void mix4(const char* A, const char* W, int
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { fw[b][i] = bf16x8{}; fa[b][i] = bf16x8{}; }
+        for (int i = 0; i < 8; ++i) {
+            fw[b][i] = bf16x8{};
+            fa[b][i] = bf16x8{};
+            if (random_frags) {
+                unsigned h = (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u) ^ (b * 97u + i * 13u);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    h = h * 1664525u + 1013904223u;
+                    fw[b][i][e] = (__bf16)(((int)(h >> 20) & 0xfff) * (1.0f / 1024.0f) - 2.0f);
+                    h = h * 1664525u + 1013904223u;
+                    fa[b][i][e] = (__bf16)(((int)(h >> 20) & 0xfff) * (1.0f / 1024.0f) - 2.0f);
+                }
+            }
+        }
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem + (lane & 15) * 64 + (lane >> 4) * 16;
     typedef __attribute__((ext_vector_type(4))) int i32x4;
     // buffer resources over A and W (raw, no swizzle): base, stride 0, num_records = 2^31, flags (DATA_FORMAT=32 etc. for gfx9 raw buffer)
@@ -113,14 +128,15 @@ __global__ __launch_bounds__(256, 1) void mix4(const char* A, const char* W, int
     if (sink && s == 12345.f) sink[0] = s;
 }
 
+static int g_rand = 0;
 template <bool MFMA, bool DMA, bool RD, bool BAR, int RDPOS, int DMAMODE = 0> void run(const char* name, const char* A, const char* W, float* sink) {
     const int K = 1024, nk = K / 32, blocks = 1024;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((mix4<MFMA, DMA, RD, BAR, RDPOS, DMAMODE>), dim3(blocks), dim3(256), 0, 0, A, W, K * 2, nk, sink);
+    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((mix4<MFMA, DMA, RD, BAR, RDPOS, DMAMODE>), dim3(blocks), dim3(256), 0, 0, A, W, K * 2, nk, sink, g_rand);
     hipEventRecord(e0);
     const int reps = 10;
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((mix4<MFMA, DMA, RD, BAR, RDPOS, DMAMODE>), dim3(blocks), dim3(256), 0, 0, A, W, K * 2, nk, sink);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((mix4<MFMA, DMA, RD, BAR, RDPOS, DMAMODE>), dim3(blocks), dim3(256), 0, 0, A, W, K * 2, nk, sink, g_rand);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -135,7 +151,10 @@ int main() {
     char *A, *W; float* sink;
     hipMalloc(&A, M * K * 2 + (1 << 20)); hipMalloc(&W, N * K * 2 + (1 << 20)); hipMalloc(&sink, 64);
     hipMemset(A, 0, M * K * 2); hipMemset(W, 0, N * K * 2);
-    run<true, false, false, false, 0>("MFMA only", A, W, sink);
+    run<true, false, false, false, 0>("MFMA only (zero operands)", A, W, sink);
+    g_rand = 1;
+    run<true, false, false, false, 0>("MFMA only (pseudo-random bf16 operands)", A, W, sink);
+    g_rand = 0;
     run<true, false, false, true, 0>("MFMA + barrier", A, W, sink);
     run<false, true, false, true, 0>("DMA (pairs adjacent) + barrier", A, W, sink);
     run<true, true, false, false, 0>("MFMA + DMA", A, W, sink);
