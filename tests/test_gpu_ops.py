@@ -205,8 +205,11 @@ def test_linear_tuned_kernel(shape, act):
 
 @pytest.mark.parametrize("B,N,H,masked", [(2, 56, 2, True), (1, 41, 2, False), (2, 200, 3, True), (1, 128, 16, False), (2, 1024, 4, True),
                                           (1, 1024, 2, False), (3, 333, 1, True)])
-def test_attention_tuned_kernel(B, N, H, masked):
+@pytest.mark.parametrize("variant", [0, 3], ids=["register_staged", "lds_dma_staged"])
+def test_attention_tuned_kernel(B, N, H, masked, variant):
     import gpu_helpers as G
+    from eraxvif5tts_amd import _lib
+    _lib.check(_lib.load().f5_tuning_set(b"attn_variant", variant))
     g = torch.Generator().manual_seed(N + H)
     qkv = G.bf16_round(torch.randn(B, N, 3, H, 64, generator=g) * 1.5)
     mask = None
@@ -214,7 +217,10 @@ def test_attention_tuned_kernel(B, N, H, masked):
         lens = torch.tensor([N, max(1, N - 13), max(1, N // 2)][:B])
         mask = torch.arange(N)[None, :] < lens[:, None]
     ref = _attn_ref(qkv, mask)
-    out = G.op_attention(P_BF16, 1, qkv, mask)
+    try:
+        out = G.op_attention(P_BF16, 1, qkv, mask)
+    finally:
+        _lib.check(_lib.load().f5_tuning_set(b"attn_variant", 0))
     # P is rounded to bf16 before the PV product and the output is bf16: 2^-9 relative each
     assert rel_l2(out, ref) < 6e-3
     valid = slice(None) if mask is None else mask
