@@ -731,7 +731,6 @@ static int persist_grid() {
 }
 int g_gemm_lean = 1;   // tuning knob ("gemm_lean"): 1 = lean epilogue on whole tiles, 0 = generic epilogue everywhere
 int g_gemm_nt = 0;     // tuning knob ("gemm_nt"): bit e = lean epilogue e (GemmEpi) uses non-temporal stores
-int g_gemm_stages = 5;   // tuning knob ("gemm_stages"): LDS ring slots of the 256x256 tile (4 = 128 KiB, 5 = 160 KiB = the whole LDS)
 
 template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmParams& p0, hipStream_t stream) {
     GemmParams p = p0;
