@@ -204,7 +204,7 @@ def main():
         total_flops = per_token * B * N * (2 if args.cfg >= 1e-5 else 1) * nfe * args.steps * world
         result["loop_tflops"] = round(total_flops / elapsed / 1e12 / world, 2)
         result["loop_mfma_frac"] = round(total_flops / elapsed / 1e12 / world / MFMA_BF16_PEAK_TFLOPS, 4)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only (the other ranks would sit in the barrier for its 15 s)
             result["cpu_baseline"] = cpu_baseline(model, N)
         print(json.dumps(result), flush=True)
     if world > 1:
