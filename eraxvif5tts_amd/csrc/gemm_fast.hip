@@ -744,7 +744,8 @@ template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmPa
     dim3 grid(nblocks), block(512);
     // persistent grid (one workgroup per CU walking tiles, next tile's first K-steps prefetched under the epilogue, bias folded into the
     // accumulator start): whole tiles with the lean epilogue's operand forms only
-    const bool persist_ok = MODE == GEMM_DENSE && (EPI == EPI_STORE_T || EPI == EPI_GATE_T || EPI == EPI_ROPE_T) && p.M % 256 == 0 &&
+    // (K >= 128: the last K-step of a tile must be one that still waits for the next tile's first stage, see the main loop)
+    const bool persist_ok = MODE == GEMM_DENSE && (EPI == EPI_STORE_T || EPI == EPI_GATE_T || EPI == EPI_ROPE_T) && p.M % 256 == 0 && p.K >= 128 &&
                             p.N % 256 == 0 && (p.ldo & 7) == 0 && p.bias && p.out_t && (p.act == ACT_NONE || p.act == ACT_GELU_TANH) &&
                             (EPI != EPI_GATE_T || (p.gate_bstride == 0 && (!p.rowmask || p.rowbits))) && (EPI != EPI_ROPE_T || p.rows_per_batch >= 128);
     if constexpr (BN == 256) {
