@@ -147,3 +147,26 @@ def test_true_depth_ragged_shapes_match_fp32_mode():
     print(f"ragged shapes, bf16 vs fp32 mode, 22 blocks x 8 steps: rel-L2 {err:.3e}")
     assert torch.isfinite(outs["bf16"]).all() and err < 2e-2
     assert torch.equal(outs["bf16"][:, :n_ref], cond.cpu())
+
+
+def test_sampler_is_run_to_run_deterministic():
+    """Ten back-to-back sample() calls (persistent GEMM grid, LDS rings, hipGraph replay) give bit-identical mels: a data race in the
+    ring bookkeeping would surface as run-to-run differences (tools/soak.py is the long form)."""
+    import bench
+    from eraxvif5tts_amd.model import CFM, DiT
+    model = bench.synth_weights(DiT(**bench.BASE_ARCH, text_num_embeds=bench.VOCAB, mel_dim=100, precision="bf16"))
+    cfm = CFM(transformer=model, mel_spec_kwargs={"mel_spec_type": "vocos"}).cuda()
+    B, N = 16, 1024
+    cond, text, lens, dur = bench.synth_batch(B, N, "cuda", seed=5)
+    dur = dur - torch.arange(B, device="cuda") * 11
+    dur[0] = N
+    g = torch.Generator().manual_seed(6)
+    y0 = torch.randn(B, N, 100, generator=g) * (torch.arange(N)[None, :, None] < dur.cpu()[:, None, None])
+    ref = None
+    for _ in range(10):
+        out, _ = cfm.sample(cond=cond, text=text, duration=dur, lens=lens, steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, y0=y0,
+                            return_trajectory=False)
+        if ref is None:
+            ref = out.clone()
+        assert torch.equal(out, ref)
+    assert torch.isfinite(ref).all()

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Determinism soak: repeat sample() at C2 (and at a ragged shape) and require bit-identical outputs every time (a data race in the
+persistent GEMM / ring bookkeeping would show up as run-to-run differences)."""
+import sys, time
+import torch
+sys.path.insert(0, ".")
+import bench
+from eraxvif5tts_amd.model import CFM, DiT
+model = bench.synth_weights(DiT(**bench.BASE_ARCH, text_num_embeds=bench.VOCAB, mel_dim=100, precision="bf16"))
+cfm = CFM(transformer=model, mel_spec_kwargs={"mel_spec_type": "vocos"}).cuda()
+for (B, N, nfe, reps) in [(32, 1024, 8, 40), (3, 777, 8, 30), (1, 1024, 8, 30), (8, 2048, 4, 10)]:
+    cond, text, lens, dur = bench.synth_batch(B, N, "cuda", seed=5)
+    if B > 1:
+        dur = dur - torch.arange(B, device="cuda") * 7
+        dur[0] = N
+    g = torch.Generator().manual_seed(6)
+    y0 = torch.randn(B, N, 100, generator=g)
+    y0 = y0 * (torch.arange(N)[None, :, None] < dur.cpu()[:, None, None])
+    ref = None
+    bad = 0
+    t0 = time.perf_counter()
+    for it in range(reps):
+        out, _ = cfm.sample(cond=cond, text=text, duration=dur, lens=lens, steps=nfe, cfg_strength=2.0, sway_sampling_coef=-1.0, y0=y0,
+                            return_trajectory=False)
+        if ref is None:
+            ref = out.clone()
+        elif not torch.equal(out, ref):
+            bad += 1
+    torch.cuda.synchronize()
+    print(f"B={B} N={N} NFE={nfe}: {reps} runs, {bad} differ from the first, finite={bool(torch.isfinite(ref).all())}, {time.perf_counter() - t0:.1f} s", flush=True)
+    assert bad == 0
+print("soak ok")
