@@ -626,12 +626,13 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
     if constexpr (VAR == 0 || VAR == 14) {
         // (VAR 14: timing-only, this schedule without the MFMAs)
         // ---- plain ring: every wave does {refill, fragment reads, MFMAs} per K-step, one barrier per K-step
+        const int abl = p.ablate;  // timing-only ablation bits (tools/narrow_ablate.py): 1 no MFMA, 2 no DMA refill, 4 fragments read once, 8 no barrier
+        bf16x8 wf[NI], af[MI];
         for (int kt = 0; kt < nk; ++kt) {
-            if (kt + D < nk) issue(kt + D);  // refills slot (kt-1) % NSTAGE: its readers passed the previous barrier
-            bf16x8 wf[NI], af[MI];
-            read_frags(kt, wf, af);
+            if (!(abl & 2) && kt + D < nk) issue(kt + D);  // refills slot (kt-1) % NSTAGE: its readers passed the previous barrier
+            if (!(abl & 4) || kt == 0) read_frags(kt, wf, af);
             if constexpr (VAR == 0) {
-                mma(wf, af);
+                if (!(abl & 1)) mma(wf, af);
             } else {
 #pragma unroll
                 for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(wf[i]));
@@ -640,8 +641,14 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
             }
             if (kt + 1 < nk) {
                 wait_pieces(min(kt + D, nk - 1) - (kt + 1));
-                __builtin_amdgcn_s_barrier();
+                if (!(abl & 8)) __builtin_amdgcn_s_barrier();
             }
+        }
+        if (abl) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(wf[i]));
+#pragma unroll
+            for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(af[j]));
         }
     } else {
         // ---- ring + staggered wave groups (the two waves that share a SIMD never run the same phase together):
@@ -717,6 +724,7 @@ int g_gemm_variant = 1;  // tuning knob (f5_tuning_set("gemm_variant", v)): 0 = 
 int g_gemm_group = 0;    // tuning knob ("gemm_group"): token tiles per L2 patch (0 = by shape, 1 = feature-tile-fastest order)
 int g_gemm_persist_grid = 0;  // tuning knob ("gemm_persist_grid"): workgroups of the persistent kernel (0 = one per CU of the device)
 int g_gemm_skew = 0;          // tuning knob ("gemm_skew"): see GemmParams::skew_ticks
+int g_gemm_fast_ablate = 0;   // tuning knob ("gemm_fast_ablate"): timing-only ablation bits of the plain-ring (narrow tile) loop
 int g_gemm_persist = 1;       // tuning knob ("gemm_persist"): 1 = whole-tile block linears run on the persistent grid
 static int persist_grid() {
     if (g_gemm_persist_grid > 0) return g_gemm_persist_grid;
@@ -737,6 +745,7 @@ template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmPa
     // L2 patch height: 8 token tiles per XCD patch; 16 for the 8-feature-tile (N = 2048) projection (tools/group_probe.py: FF1 985 -> 1 020 TFLOP/s)
     p.tile_group = g_gemm_group > 0 ? g_gemm_group : (cdiv(p.N, BN) == 8 ? 16 : 8);
     p.lean_epi = g_gemm_lean;
+    p.ablate = g_gemm_fast_ablate;
     p.skew_ticks = g_gemm_skew;
     p.nt_store = g_gemm_nt >= 256 ? (g_gemm_nt >> 8) : ((g_gemm_nt >> EPI) & 1);  // >= 256: store flavour experiment (2 = sc0 sc1, 3 = sc0 sc1 nt) for every epilogue
     const int tiles_m = cdiv(p.M, 256), tiles_n = cdiv(p.N, BN);
