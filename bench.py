@@ -2,30 +2,41 @@
 """Headline benchmark: mel-frames/s of the F5-TTS flow-matching sampler (CFM.sample: 32 Euler steps x (cond + uncond) DiT
 evaluations, CFG 2, sway -1) on MI355X, at BASELINE.json's C2: F5TTS_Base, bf16, batch 32, seq_len 1024, NFE 32.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+  python bench.py --gpus N --steps K --warmup W [--scaling strong|weak] [--workload C2|C4|vocos]
 
-A "step" is one full sample() over one synthetic batch of 32 fixed-length utterances that is already resident in HBM.
-Multi-GPU: utterance batches are sharded over ranks (one process per GPU, full weight replica, no collective inside the
-ODE loop); the finished mels are all-gathered with RCCL inside the timed region.  Weak scaling: 32 utterances per GPU.
+A "step" is one full sample() over one synthetic batch of fixed-length utterances that is already resident in HBM.
+
+Multi-GPU (--gpus N > 1): one process per GPU over RCCL (torch.distributed backend "nccl").  Started under torchrun (the driver's
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`) the ranks are used as given; started as a plain
+`python bench.py --gpus N`, the parent process -- before it makes ANY GPU call -- launches that same torchrun command as a child
+process, relays rank 0's JSON line and exits with the child's code.  A WORLD_SIZE that contradicts --gpus is an error.
+  --scaling strong (default, C3 of SURVEY.md 8d): the SAME 32 utterances are split contiguously over the ranks (32/N per GPU, the
+      reference's eval_infer_batch.py:163 split) and the finished mels are all-gathered inside the timed region;
+  --scaling weak: 32 utterances per GPU.
+There is no collective inside the ODE loop; the all_gather of the finished mels is the only one.
 
 One JSON line on rank 0 with the driver's contract fields plus
-  "roofline"      the dominant kernel (fused QKV projection GEMM, one shape per launch): algorithmic FLOPs per launch /
-                  mean launch time measured here with HIP events (f5_bench_gemm_site), vs the 2.5 PFLOP/s dense bf16 MFMA peak
+  "roofline"      the dominant kernel (fused QKV projection GEMM): algorithmic FLOPs per launch / mean launch time measured here
+                  with HIP event pairs on the launch stream, vs the 2.5 PFLOP/s dense bf16 MFMA peak; "kernels" lists the same
+                  in-situ measurement for every kernel of a DiT block (GEMMs and attention against MFMA peak, the LayerNorm passes
+                  against the 8 TB/s HBM peak); "traffic" is read from the newest profiles/*traffic*.json (a recorded rocprofv3 PMC
+                  pass, named in "traffic_source"), null when there is none for this shape;
   "cpu_baseline"  the CPU oracle (oracle/cpu_ref.py, plain fp32 torch; the reference itself cannot travel) timed on this
-                  host's cores on a bounded sample, scaled linearly to NFE 32.
+                  host's cores on a bounded sample, scaled linearly to the workload's NFE.
+  --workload vocos (C5): Vocos.decode on [B, 100, T] (T = 683 at B = 32, or --seq-len T), frames/s, HBM roofline of the ISTFT head.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import glob
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -33,12 +44,15 @@ sys.path.insert(0, ROOT)
 BASE_ARCH = dict(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, text_mask_padding=False, conv_layers=4, pe_attn_head=1)
 VOCAB = 2545
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
-QKV_TRAFFIC_BYTES = int((320754.9 * 2 + 393299.5) * 1024)  # profiles/r1_08_c2_persistent_grid_kernel_stats.md (PMC passes)
+MFMA_F32_PEAK_TFLOPS = 157.3    # fp32-input MFMA (the vocoder backbone)
+HBM_PEAK_GBS = 8000.0           # HBM3E spec (6.3 TB/s achievable, same guide)
+WORKLOADS = {"C2": (32, 1024), "C4": (8, 4096)}
 
 
 def synth_weights(model, seed=0):
     """Random-init F5TTS_Base (no checkpoint exists offline); zero-initialised tensors re-randomised (sigma 0.02) so the
     network is not degenerate."""
+    import torch
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for _, p in model.named_parameters():
@@ -49,6 +63,7 @@ def synth_weights(model, seed=0):
 
 def synth_batch(B, N, device, seed=0):
     """SURVEY.md 8(d): cond mel ~ N(-3, 2^2) clipped to [ln 1e-5, 3], N_ref = N//3, text ids uniform, length N//6."""
+    import torch
     g = torch.Generator().manual_seed(seed)
     n_ref = N // 3
     cond = (torch.randn(B, n_ref, 100, generator=g) * 2 - 3).clamp(math.log(1e-5), 3.0)
@@ -58,9 +73,8 @@ def synth_batch(B, N, device, seed=0):
     return cond.to(device), text.to(device), lens.to(device), duration.to(device)
 
 
-def cpu_baseline(model, N, seconds_hint=20):
-    """CPU oracle on the host cores: B=1, N, NFE=1 (2 network evaluations), scaled linearly in NFE to 32."""
-    from oracle import cpu_ref  # checker, used here only as the timed CPU baseline
+def _host_cores():
+    import torch
     # the GPU box exposes every host core but a 1-GPU job owns a 16-core share; oversubscribing torch's pool is far slower
     try:
         avail = len(os.sched_getaffinity(0))
@@ -68,28 +82,141 @@ def cpu_baseline(model, N, seconds_hint=20):
         avail = os.cpu_count() or 1
     cores = max(1, min(16, avail))
     torch.set_num_threads(cores)
+    return cores
+
+
+def cpu_baseline(model, N, nfe_full):
+    """CPU oracle on the host cores: B=2 (B=1 for the long form), N, NFE=2 (NFE=1), scaled linearly in NFE."""
+    import torch
+    from oracle import cpu_ref  # checker, used here only as the timed CPU baseline
+    cores = _host_cores()
     W = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     g = torch.Generator().manual_seed(1)
     n_ref = N // 3
-    bs, nfe = 2, 2
+    bs, nfe = (2, 2) if N <= 1024 else (1, 1)
     cond = (torch.randn(bs, n_ref, 100, generator=g) * 2 - 3).clamp(math.log(1e-5), 3.0)
     text = torch.randint(0, VOCAB, (bs, N // 6), generator=g)
     t0 = time.perf_counter()
     cpu_ref.sample(W, BASE_ARCH, cond, text, N, steps=nfe, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0, return_trajectory=False)
     dt = time.perf_counter() - t0
-    value = bs * N / (dt * 32 / nfe)
+    value = bs * N / (dt * nfe_full / nfe)
     return {"value": round(value, 3), "unit": "mel-frames/s", "cores": cores, "kind": "port",
             "sample": f"oracle/cpu_ref.sample fp32 torch, B={bs} N={N} NFE={nfe} CFG=2 ({2 * nfe} network evaluations of {bs} utterances, "
-                      f"{dt:.1f} s), scaled linearly to NFE=32"}
+                      f"{dt:.1f} s), scaled linearly to NFE={nfe_full}"}
+
+
+def recorded_traffic(kernel_key, rows, N):
+    """HBM-side bytes per launch of `kernel_key` from the newest profiles/*traffic*.json (written by tools/pmc_traffic.py from separate
+    rocprofv3 --pmc passes: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE).  Returns (bytes | None, source | None)."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+        except (OSError, ValueError):
+            continue
+        e = rec.get(kernel_key)
+        if e and e.get("rows") == rows and e.get("seq_len") == N:
+            return int(e["bytes_per_launch"]), os.path.relpath(path, ROOT)
+    return None, None
+
+
+def launch_children(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a torchrun child BEFORE this process touches the GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.lstrip().startswith('{"metric"'):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks exited without a result line\n")
+        rc = 1
+    if line is not None:
+        print(line, flush=True)
+    sys.exit(rc)
+
+
+def bench_vocos(args, dev):
+    """C5: Vocos.decode on the generated part of a C2 (T = 683) or C4 (T = 2731) batch."""
+    import torch
+    from eraxvif5tts_amd import _lib
+    from eraxvif5tts_amd.vocos import Vocos
+    from oracle import cpu_ref
+    lib = _lib.load()
+    T = args.seq_len if args.seq_len else 683
+    B = args.batch if args.batch else (32 if T <= 1024 else 8)
+    V = cpu_ref.random_vocos_weights(seed=3)  # random init of the vocos-mel-24khz shape (no checkpoint offline)
+    voc = Vocos()
+    voc.load_state_dict({k: t for k, t in V.items() if k in voc.state_dict()}, strict=False)
+    voc = voc.to(dev)
+    g = torch.Generator().manual_seed(0)
+    mel = (torch.randn(B, 100, T, generator=g) * 2 - 3).clamp(math.log(1e-5), 3.0).to(dev)
+    for _ in range(args.warmup):
+        wave = voc.decode(mel)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wave = voc.decode(mel)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert torch.isfinite(wave).all()
+    frames = B * T * args.steps
+    audio_s = B * (T - 1) * 256 / 24000.0 * args.steps
+    # ISTFT head alone (HBM-bound): HIP events around f5_vocoder_istft_head on this stream
+    head = torch.randn(B, T, 1026, generator=g).to(dev) * 0.5
+    hw = voc.istft_head(head)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    iters = 20
+    e0.record()
+    for _ in range(iters):
+        hw = voc.istft_head(head)
+    e1.record()
+    torch.cuda.synchronize()
+    head_ms = e0.elapsed_time(e1) / iters
+    head_bytes = B * T * (1026 * 4 + 256 * 4)  # SURVEY 8(d): read 1026 coefficients + write 256 samples per frame = 5.1 KB
+    achieved = head_bytes / (head_ms * 1e-3) / 1e9
+    flops = 2.0 * B * T * (7 * 100 * 512 + 8 * (7 * 512 + 2 * 512 * 1536) + 512 * 1026)
+    result = {
+        "metric": "vocoder mel-frames/s", "value": round(frames / elapsed, 2), "unit": "mel-frames/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rtf": round(elapsed / audio_s, 7),
+        "config": {"workload": f"C5 Vocos.decode (vocos-mel-24khz shape, random init): mel [B={B}, 100, T={T}] -> wave [B, {(T - 1) * 256}]",
+                   "global_batch": B, "frames": T},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": None, "kernel": "ISTFT head (spectrum -> inverse real DFT -> window -> overlap-add)",
+                     "launch": f"{head_bytes / 1e6:.1f} MB algorithmic (5.1 KB per frame) in {head_ms:.4f} ms, mean of {iters} calls (HIP events)",
+                     "backbone_tflops_f32": round(flops * args.steps / elapsed / 1e12, 2), "backbone_peak_f32": MFMA_F32_PEAK_TFLOPS},
+    }
+    if not args.no_cpu_baseline:
+        cores = _host_cores()
+        bs = 2 if T <= 1024 else 1
+        cm = mel[:bs].cpu()
+        t0 = time.perf_counter()
+        cpu_ref.vocos_decode(V, cm)
+        dt = time.perf_counter() - t0
+        result["cpu_baseline"] = {"value": round(bs * T / dt, 2), "unit": "mel-frames/s", "cores": cores, "kind": "port",
+                                  "sample": f"oracle/cpu_ref.vocos_decode fp32 torch, B={bs} T={T} ({dt:.2f} s)"}
+    print(json.dumps(result), flush=True)
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
-    ap.add_argument("--seq-len", type=int, default=1024)
+    ap.add_argument("--workload", default="C2", choices=["C2", "C4", "vocos"])
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--batch", type=int, default=0, help="utterances (per GPU with --scaling weak, in total with strong); 0 = the workload's")
+    ap.add_argument("--seq-len", type=int, default=0)
     ap.add_argument("--nfe", type=int, default=32)
     ap.add_argument("--cfg", type=float, default=2.0)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
@@ -97,9 +224,21 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus is None:
+        args.gpus = int(env_world) if env_world else 1
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if env_world is None and args.gpus > 1:
+        launch_children(args)  # never returns; nothing in this process has touched the GPU
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} contradicts WORLD_SIZE={world} (launch with --nproc-per-node {args.gpus}, or drop --gpus)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+    backend = "none"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -116,22 +255,43 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
 
     from eraxvif5tts_amd import _lib
+    from eraxvif5tts_amd.eval.sharded import split_between_processes
     from eraxvif5tts_amd.model import CFM, DiT
     _lib.require_gpu()
     lib = _lib.load()
 
-    B, N, nfe = args.batch, args.seq_len, args.nfe
+    if args.workload == "vocos":
+        if world > 1:
+            sys.exit("bench.py: --workload vocos is a single-GPU measurement")
+        return bench_vocos(args, dev)
+
+    wl_B, wl_N = WORKLOADS[args.workload]
+    N, nfe = args.seq_len or wl_N, args.nfe
+    B_req = args.batch or wl_B
+    if args.scaling == "strong" and world > 1:
+        # C3: the same B_req utterances, split contiguously over the ranks as eval_infer_batch.py:163 splits its list
+        mine = split_between_processes(list(range(B_req)), rank, world)
+        B, B_total = len(mine), B_req
+        if B == 0:
+            sys.exit(f"bench.py: {B_req} utterances cannot feed {world} ranks")
+    else:
+        mine = list(range(rank * B_req, (rank + 1) * B_req))
+        B, B_total = B_req, B_req * world
     model = synth_weights(DiT(**BASE_ARCH, text_num_embeds=VOCAB, mel_dim=100, precision=args.precision))
     cfm = CFM(transformer=model, mel_spec_kwargs={"mel_spec_type": "vocos"}, odeint_kwargs={"method": "euler"}).to(dev)
-    cond, text, lens, duration = synth_batch(B, N, dev, seed=rank)
+    # one global synthetic batch; every rank keeps its contiguous share (identical utterances whatever the rank count)
+    cond, text, lens, duration = [t[mine[0]:mine[-1] + 1].contiguous() for t in synth_batch(B_total, N, dev, seed=0)]
 
-    gathered = [torch.empty(B, N, 100, device=dev) for _ in range(world)] if world > 1 else None
+    bmax = -(-B_total // world)
+    gathered = [torch.zeros(bmax, N, 100, device=dev) for _ in range(world)] if world > 1 else None
+    pad = torch.zeros(bmax, N, 100, device=dev) if world > 1 else None
 
     def step():
         out, _ = cfm.sample(cond=cond, text=text, duration=duration, lens=lens, steps=nfe, cfg_strength=args.cfg,
                             sway_sampling_coef=-1.0, seed=0, return_trajectory=False, use_graph=not args.no_graph)
         if world > 1:
-            dist.all_gather(gathered, out.contiguous())  # the only collective of the path: finished mels over RCCL/xGMI
+            pad[:B].copy_(out)
+            dist.all_gather(gathered, pad)  # the only collective of the path: finished mels over RCCL/xGMI
         return out
 
     for _ in range(args.warmup):
@@ -147,50 +307,81 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    devices = [torch.cuda.get_device_name(dev)]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        names = [None] * world
+        dist.all_gather_object(names, f"rank{rank}:cuda{torch.cuda.current_device()}:{devices[0]}")
+        devices = names
     assert torch.isfinite(out).all(), "non-finite mel output"
 
-    frames = B * N * args.steps * world
+    frames = B_total * N * args.steps
     value = frames / elapsed
-    gen_audio_s = B * (N - N // 3) * 256 / 24000.0 * args.steps * world
+    gen_audio_s = B_total * (N - N // 3) * 256 / 24000.0 * args.steps
     result = {
         "metric": "mel-frames/s", "value": round(value, 2), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": args.scaling if world > 1 else "weak",
         "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "rtf": round(elapsed / gen_audio_s, 6),
-        "config": {"workload": f"C2 F5TTS_Base random-init, CFM.sample euler NFE={nfe} CFG={args.cfg:g} sway=-1, batch {B}/GPU x seq_len {N} "
-                               f"(N_ref={N // 3}), hipGraph={'off' if args.no_graph else 'on'}",
-                   "global_batch": B * world, "seq_len": N, "nfe": nfe, "parallelism": f"utterance-sharded dp{world}"},
+        "config": {"workload": f"{args.workload if (N, B_req) == (wl_N, wl_B) else 'custom'} F5TTS_Base random-init, CFM.sample euler NFE={nfe} "
+                               f"CFG={args.cfg:g} sway=-1, {B_total} utterances x seq_len {N} (N_ref={N // 3}), "
+                               f"{'split ' + str(B) + ' per GPU' if world > 1 else 'one GPU'}, hipGraph={'off' if args.no_graph else 'on'}",
+                   "global_batch": B_total, "per_gpu_batch": B, "seq_len": N, "nfe": nfe, "parallelism": f"utterance-sharded dp{world}"},
+        "distributed": {"world_size": dist.get_world_size() if world > 1 else 1, "backend": backend, "devices": devices},
     }
 
     if rank == 0:
-        # ---- roofline of the dominant kernel: fused QKV projection (29 % of the FLOPs, one shape per launch)
-        rows = 2 * B * N if args.cfg >= 1e-5 else B * N
-        flops = 2.0 * rows * (3 * 16 * 64) * 1024
-        # in situ: one extra eager sample() with a HIP event pair around every fused-QKV launch (22 blocks x nfe evaluations),
-        # on the stream the kernels run on; this is the same launch rocprofv3 averages in profiles/
+        cfg_on = args.cfg >= 1e-5
+        rows = (2 if cfg_on else 1) * B * N
+        inner, D, ff, depth = 16 * 64, 1024, 2048, BASE_ARCH["depth"]
+        # in situ: one extra eager sample() with a HIP event pair around every block kernel (6 per block + 3 per evaluation),
+        # on the stream the kernels run on; these are the same launches rocprofv3 averages in profiles/
         plan = model.plan(B, N, nfe)
         ms, cnt = C.c_float(0.0), C.c_int(0)
-        _lib.check(lib.f5_plan_timing_begin(plan, BASE_ARCH["depth"] * nfe), "timing_begin")
+        _lib.check(lib.f5_plan_timing_begin(plan, (7 * depth + 4) * nfe), "timing_begin")
         cfm.sample(cond=cond, text=text, duration=duration, lens=lens, steps=nfe, cfg_strength=args.cfg, sway_sampling_coef=-1.0, seed=0,
                    return_trajectory=False, use_graph=False)
         _lib.check(lib.f5_plan_timing_end(plan, C.byref(ms), C.byref(cnt), _lib.stream_ptr()), "timing_end")
-        achieved = flops / (ms.value * 1e-3) / 1e12
-        # isolated: back-to-back launches of the same kernel on cold operands (f5_bench_gemm_site), for reference
-        iso = C.c_float(0.0)
-        iso_ok = lib.f5_bench_gemm_site(1, 0, rows, N, 1024, 16, 2048, 10, C.byref(iso), _lib.stream_ptr()) == 0
+        flops_qkv = 2.0 * rows * (3 * inner) * D
+        achieved = flops_qkv / (ms.value * 1e-3) / 1e12
+
+        def site(i):
+            a, n = C.c_float(0.0), C.c_int(0)
+            _lib.check(lib.f5_plan_timing_site(plan, i, C.byref(a), C.byref(n)), "timing_site")
+            return a.value, n.value
+        es = 2 if args.precision == "bf16" else 4
+        work = {  # algorithmic work per launch: FLOP for the MFMA-bound kernels, bytes for the HBM-bound LayerNorm passes
+            "qkv": ("mfma", flops_qkv), "attention": ("mfma", 4.0 * rows * N * inner), "attn_out": ("mfma", 2.0 * rows * D * inner),
+            "ff1": ("mfma", 2.0 * rows * ff * D), "ff2": ("mfma", 2.0 * rows * D * ff), "conv31": ("mfma", 2.0 * rows * D * 64 * 31),
+            "input_proj": ("mfma", 2.0 * rows * D * 100),
+            "ln1": ("hbm", rows * D * (4 + es + es)),               # read x (f32) + the FF branch, write the normalised rows
+            "ln2": ("hbm", rows * D * (4 + es + es + 4 + es)),      # read x + both branches, write x and the normalised rows
+        }
+        kernels = []
+        for i, name in enumerate(_lib.SITES):
+            t_ms, n = site(i)
+            if n == 0 or t_ms <= 0:
+                continue
+            bound, w = work[name]
+            if bound == "mfma":
+                a = w / (t_ms * 1e-3) / 1e12
+                kernels.append({"kernel": name, "bound": "mfma", "work": round(w / 1e9, 2), "work_unit": "GFLOP", "ms": round(t_ms, 4),
+                                "launches": n, "achieved": round(a, 1), "unit": "TFLOP/s", "frac": round(a / MFMA_BF16_PEAK_TFLOPS, 4)})
+            else:
+                a = w / (t_ms * 1e-3) / 1e9
+                kernels.append({"kernel": name, "bound": "hbm", "work": round(w / 1e6, 1), "work_unit": "MB", "ms": round(t_ms, 4),
+                                "launches": n, "achieved": round(a, 1), "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4)})
+        traffic, traffic_src = recorded_traffic("qkv", rows, N)
         result["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
-                              # HBM-side bytes per launch from the rocprofv3 PMC passes recorded in profiles/r1_08_* (FETCH_SIZE x 2 on gfx950
-                              # + WRITE_SIZE); only meaningful for the default C2 shape, null otherwise
-                              "traffic": QKV_TRAFFIC_BYTES if (rows == 65536 and N == 1024) else None,
+                              "traffic": traffic, "traffic_source": traffic_src,
                               "kernel": "gemm_fast_kernel<256,128,DENSE,QKV+RoPE epilogue,persistent grid>",
-                              "launch": f"M={rows} N=3072 K=1024, {flops / 1e9:.1f} GFLOP, {ms.value:.4f} ms mean over {cnt.value} launches inside an "
+                              "launch": f"M={rows} N=3072 K=1024, {flops_qkv / 1e9:.1f} GFLOP, {ms.value:.4f} ms mean over {cnt.value} launches inside an "
                                         f"eager sample() (HIP event pairs on the launch stream)",
-                              "isolated_tflops": round(flops / (iso.value * 1e-3) / 1e12, 2) if iso_ok else None}
+                              "kernels": kernels}
         # what the matrix pipe itself sustains on THIS device (register-resident MFMA stream, no memory traffic): clock-limited with
         # zero operands, power-limited with realistic ones -- context for `frac`, whose denominator stays the data-sheet peak
         sus = {}
@@ -201,11 +392,11 @@ def main():
         result["roofline"]["mfma_sustained_tflops"] = sus or None
         # whole-loop MFMA fraction from the algorithmic FLOPs of SURVEY.md 8(d)
         per_token = 378.9e6 + 90112.0 * N
-        total_flops = per_token * B * N * (2 if args.cfg >= 1e-5 else 1) * nfe * args.steps * world
+        total_flops = per_token * B_total * N * (2 if cfg_on else 1) * nfe * args.steps
         result["loop_tflops"] = round(total_flops / elapsed / 1e12 / world, 2)
         result["loop_mfma_frac"] = round(total_flops / elapsed / 1e12 / world / MFMA_BF16_PEAK_TFLOPS, 4)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only (the other ranks would sit in the barrier for its 15 s)
-            result["cpu_baseline"] = cpu_baseline(model, N)
+            result["cpu_baseline"] = cpu_baseline(model, N, nfe)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -11,6 +11,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libf5hip.so")
 
 F5_PREC_BF16, F5_PREC_FP32 = 0, 1
 F5_ODE_EULER, F5_ODE_MIDPOINT = 0, 1
+F5_ROPE_ADJACENT, F5_ROPE_HALF_SPLIT = 0, 1
+SITES = ("qkv", "attention", "attn_out", "ff1", "ff2", "ln1", "ln2", "conv31", "input_proj")  # F5_SITE_* order
 ACT = {"none": 0, "gelu_tanh": 1, "gelu_erf": 2, "mish": 3}
 
 
@@ -20,7 +22,7 @@ class F5HipError(RuntimeError):
 
 class DitConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("dim", "depth", "heads", "dim_head", "ff_inner", "mel_dim", "text_num_embeds", "text_dim",
-                                         "conv_layers", "text_mask_padding", "pe_attn_head", "qk_norm", "long_skip", "precision")]
+                                         "conv_layers", "text_mask_padding", "pe_attn_head", "qk_norm", "long_skip", "precision", "rope_layout")]
 
 
 class VocosConfig(C.Structure):
@@ -50,6 +52,7 @@ _PROTOS = {
     "f5_dit_forward": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "f5_plan_timing_begin": (_I, [_P, _I]),
     "f5_plan_timing_end": (_I, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int), _P]),
+    "f5_plan_timing_site": (_I, [_P, _I, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "f5_plan_set_tap": (_I, [_P, C.c_char_p, _P]),
     "f5_plan_set_option": (_I, [_P, C.c_char_p, _I]),
     "f5_duration_predict": (_I, [C.POINTER(DurationWeights), _I, _I, _P, _I, _P, _P, _P, _P]),

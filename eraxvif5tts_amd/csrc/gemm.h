@@ -47,9 +47,6 @@ struct GemmParams {
     // CONV31: channels per group (dim/16) and the padded input-channel window one 64-channel output tile reads
     int conv_cg, conv_win;
     int tile_group;  // tuned kernel: token tiles per L2 patch (set by the launcher)
-    int nt_store;    // tuned kernel, lean epilogue: non-temporal stores (set by the launcher)
-    int skew_ticks;  // persistent tuned kernel, experiment: every other workgroup starts this many 100 MHz ticks late (de-synchronises the store bursts)
-    int ablate;      // gemm_big.hip timing ablations (bit 0: no MFMA, 1: no DMA refill, 2: no fragment reads, 3: no epilogue)
     int lean_epi;    // tuned kernel: whole tiles take the lean epilogue (set by the launcher; 0 = always the generic one)
 };
 
@@ -57,9 +54,6 @@ struct GemmParams {
 int launch_gemm(const GemmParams& p, int precision, int mode, int epi, int kernel_kind, hipStream_t stream);
 // true when the tuned kernel can run this problem (bf16, tile-multiple shapes, supported epilogue)
 bool gemm_fast_supported(const GemmParams& p, int precision, int mode, int epi);
-// 4-wave kernel with 128 x 128 outputs per wave (gemm_big.hip): the DiT block linears with whole-feature-tile shapes
-bool gemm_big_supported(const GemmParams& p, int mode, int epi);
-int launch_gemm_big(const GemmParams& p, int epi, hipStream_t stream);
 // dedicated kernel for the dim-1024 grouped Conv1d(k = 31) of ConvPositionEmbedding (conv31.hip); GemmParams as for GEMM_CONV31
 bool conv31_supported(const GemmParams& p, int precision, int epi);
 int launch_conv31(const GemmParams& p, hipStream_t stream);

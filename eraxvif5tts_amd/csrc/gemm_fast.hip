@@ -10,7 +10,9 @@
 //   * schedules (template VAR): 1 = the two waves of a SIMD staggered by one barrier interval (one feeds the matrix pipe while
 //     the other issues DMA and reads fragments); 30 = the same on a PERSISTENT grid (one workgroup per CU walks tiles, the DMA
 //     front crosses into the next tile under the epilogue) -- the production schedule for whole-tile block linears;
-//     0 = plain ring (narrow tiles); 2 / 3 / 20 and 10..17, 31, 32 = measured alternatives and timing-only ablations;
+//     0 = plain ring (narrow tiles).  Measured alternatives (paired / split DMA issue, half-slab ring, store flavours, a 4-wave
+//     128x128-per-wave kernel) and the timing-only ablation builds are recorded in DESIGN.md and profiles/r1_06..r1_10; their code
+//     left the library in round 2 (git history: 6761115);
 //   * every accumulator starts from its feature's bias (identical fp32 sums in every variant and tile width); whole tiles take
 //     the lean store-only epilogue, ragged tiles the generic one;
 //   * LDS image is lane-linear (a DMA instruction writes 16 rows x 64 B); bank conflicts of the ds_read_b128 fragment
@@ -53,8 +55,9 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
         tm0 = tile_m * BM;
         tn0 = tile_n * BN;
     };
-    constexpr bool P30 = VAR == 30 || VAR == 33;  // production persistent schedule (33: timing-only, without the epilogue's stores)
-    constexpr bool PERSIST = VAR >= 30;  // (31 / 32: timing-only ablations without the epilogue's stores / without the epilogue)  // persistent grid: a block walks tiles bid, bid + gridDim.x, ... and prefetches across tile boundaries
+    static_assert(VAR == 0 || VAR == 1 || VAR == 30, "schedules: 0 plain ring, 1 staggered wave groups, 30 staggered + persistent grid");
+    constexpr bool P30 = VAR == 30;      // production persistent schedule
+    constexpr bool PERSIST = VAR == 30;  // persistent grid: a block walks tiles bid, bid + gridDim.x, ... and prefetches across tile boundaries
     int m0, n0;                          // tile being computed (epilogue side)
     tile_mn(blockIdx.x, m0, n0);
 
@@ -101,45 +104,10 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
     const int win0 = MODE == GEMM_CONV31 ? (n0 / p.conv_cg) * p.conv_cg : 0;
     const int L = p.rows_per_batch;
 
-    // ---- VAR 20 ("half-slab ring"): the ring unit is {128 token rows + 128 weight rows} x 64 k, so every DMA piece is 8 rows of
-    //      one whole, aligned 128-byte line (measured: +45 % LDS-DMA rate vs 16 rows x 64 B).  K-step t (64 deep) = half-slabs
-    //      2t (rows 0-127 of both operands) and 2t+1 (rows 128-255); it is consumed as two 32-deep sub-steps.
-    [[maybe_unused]] const bf16_t* hs_a[2][2];  // [half r][piece j]
-    [[maybe_unused]] const bf16_t* hs_w[2][2];
-    if constexpr (VAR == 20 || VAR == 21) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = (wave * 2 + j) * 8 + (lane >> 3);          // row inside the half-slab operand (0..127)
-            const int lc = (lane & 7) ^ ((row >> 1) & 7);              // logical 16-byte chunk kept at this physical slot
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                int gmr = m0 + 128 * r + row;
-                if (gmr >= p.M) gmr = p.M - 1;
-                if (p.a_row_mod > 0) gmr %= p.a_row_mod;
-                hs_a[r][j] = A + (size_t)gmr * p.lda + lc * 8;
-                int gnr = n0 + 128 * r + row;
-                if (gnr >= p.N) gnr = p.N - 1;
-                hs_w[r][j] = W + (size_t)gnr * p.ldw + lc * 8;
-            }
-        }
-    }
-
     // piece ids of one K-step for this wave: 0,1 = activation pieces, 2.. = weight pieces
     auto issue_piece = [&](int slot, int kt, int piece) {
         char* sbase = smem + slot * STAGE;
-        if constexpr (VAR == 20 || VAR == 21) {
-            // kt = half-slab index h: K range [64 * (h >> 1), +64), operand rows 128 * (h & 1) ..
-            const int t = kt >> 1, r = kt & 1;
-            if (piece < 2)
-                dma16((r ? hs_a[1][piece] : hs_a[0][piece]) + (size_t)t * 64, sbase + (wave * 2 + piece) * 1024);
-            else
-                dma16((r ? hs_w[1][piece - 2] : hs_w[0][piece - 2]) + (size_t)t * 64, sbase + A_BYTES + (wave * 2 + piece - 2) * 1024);
-        } else if constexpr (VAR == 13) {
-            // timing-only: same bytes per piece, but 8 rows x 128 B (whole, aligned cache lines) instead of 16 rows x 64 B
-            const bf16_t* base = piece < 2 ? A + (size_t)(m0 + (wave * 2 + piece) * 8 + (lane >> 3)) * p.lda
-                                           : W + (size_t)(n0 + (wave * 2 + piece - 2) * 8 + (lane >> 3)) * p.ldw;
-            dma16(base + (size_t)(kt % (nk / 2)) * (2 * BK) + (lane & 7) * 8, sbase + (piece < 2 ? (wave * 2 + piece) * 1024 : A_BYTES + w_piece[piece - 2] * 1024));
-        } else if constexpr (MODE == GEMM_DENSE) {
+        if constexpr (MODE == GEMM_DENSE) {
             if (piece < 2)
                 dma16(a_src[piece] + (size_t)kt * BK, sbase + (wave * 2 + piece) * 1024);
             else
@@ -161,17 +129,6 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
 #pragma unroll
         for (int pc = 0; pc < PPW; ++pc) issue_piece(kt % NSTAGE, kt, pc);
     };
-    // VAR 2: K-steps are fetched in (even, odd) pairs, piece by piece.  The two 64-byte halves of every 128-byte line are then
-    // requested by ADJACENT instructions, which the vector L1 merges into one line fetch (tools/dma_probe.hip: 0.39 us per K-step
-    // of operand feed instead of 0.58 us; with 64 cycles between the halves the gain is gone).
-    [[maybe_unused]] auto issue_pair = [&](int kt) {
-#pragma unroll
-        for (int pc = 0; pc < PPW; ++pc) {
-            issue_piece(kt % NSTAGE, kt, pc);
-            issue_piece((kt + 1) % NSTAGE, kt + 1, pc);
-        }
-    };
-
     // ---- fragment read offsets (bytes inside a stage)
     const int fr = lane & 15, fq = lane >> 4;
     const int c0 = (fq ^ ((0 - (fr >> 2)) & 3)) * 16;
@@ -225,18 +182,6 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
     };
 
     auto read_frags = [&](int kt, bf16x8 (&wf)[NI], bf16x8 (&af)[MI]) {
-        if constexpr (VAR == 20 || VAR == 21) {
-            // sub-step kt = 2t + ks of K-step t: tokens of this wave live in half-slab 2t + wm, its weight rows in 2t + (wn >> 1)
-            const int t2 = kt & ~1, ks = kt & 1;
-            const int chunk = ((4 * ks + fq) ^ (fr >> 1)) * 16;
-            const char* sa = smem + ((t2 + wm) % NSTAGE) * STAGE + fr * 128 + chunk;
-            const char* sw = smem + ((t2 + (wn >> 1)) % NSTAGE) * STAGE + A_BYTES + ((wn & 1) * 64 + fr) * 128 + chunk;
-#pragma unroll
-            for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sw + i * 2048);
-#pragma unroll
-            for (int j = 0; j < MI; ++j) af[j] = *reinterpret_cast<const bf16x8*>(sa + j * 2048);
-            return;
-        }
         const char* sb = smem + (PERSIST ? kt : kt % NSTAGE) * STAGE;  // PERSIST: the caller passes the ring slot
 #pragma unroll
         for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + w_off + i * 1024);
@@ -265,13 +210,6 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
     // Loads (row mask, RoPE table, addend / residual) are issued in groups BEFORE any store of the group: vmcnt retires
     // in order, so a load issued behind a store would also wait for that store's round trip.
     auto generic_epilogue = [&]() {
-    if constexpr (VAR == 32 || VAR == 15) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(acc[i][j]));
-        return;
-    }
     constexpr int JG = (EPI == EPI_RESID || EPI == EPI_GATE_T) ? 2 : (MI >= 4 ? 4 : MI);  // token tiles per load group (register budget)
     static_for<MI / JG>([&](auto gc) {
         constexpr int j0 = decltype(gc)::value * JG;
@@ -358,10 +296,7 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
                     static_for<NI / 2>([&](auto hc) {
                         constexpr int i = decltype(hc)::value * 2;
                         const u32x4 q = pair_swap(to_bf16x4(vals[i]), to_bf16x4(vals[i + 1]));
-                        if constexpr (VAR == 31)
-                            asm volatile("" ::"v"(q));
-                        else if (okm[jj])
-                            *reinterpret_cast<u32x4*>(orow + nwide + 32 * (i / 2)) = q;
+                        if (okm[jj]) *reinterpret_cast<u32x4*>(orow + nwide + 32 * (i / 2)) = q;
                     });
                 } else {
                     static_for<NI>([&](auto ic) {
@@ -449,26 +384,13 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
                 q1 = keep ? q1 : u32x4{0u, 0u, 0u, 0u};
             }
             bf16_t* o = orow + j * jstride;
-            if constexpr (VAR == 16 || VAR == 33) {  // timing-only: the lean epilogue without its stores
-                asm volatile("" ::"v"(q0), "v"(q1), "v"(o));
-            } else if (p.nt_store == 2) {  // experiment: write-through, system-scope stores (sc0 sc1): the lines do not stay dirty in L2
-                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(o), "v"(q0) : "memory");
-                asm volatile("global_store_dwordx4 %0, %1, off offset:64 sc0 sc1" ::"v"(o), "v"(q1) : "memory");
-            } else if (p.nt_store == 3) {  // experiment: sc0 sc1 nt
-                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(o), "v"(q0) : "memory");
-                asm volatile("global_store_dwordx4 %0, %1, off offset:64 sc0 sc1 nt" ::"v"(o), "v"(q1) : "memory");
-            } else if (VAR == 17 || p.nt_store) {  // streaming stores: the output tile does not displace the operand slices in L2
-                __builtin_nontemporal_store(q0, reinterpret_cast<u32x4*>(o));
-                __builtin_nontemporal_store(q1, reinterpret_cast<u32x4*>(o + 32));
-            } else {
-                *reinterpret_cast<u32x4*>(o) = q0;
-                *reinterpret_cast<u32x4*>(o + 32) = q1;
-            }
+            *reinterpret_cast<u32x4*>(o) = q0;
+            *reinterpret_cast<u32x4*>(o + 32) = q1;
         });
     };
     // whole tile + the operand forms the lean epilogue assumes; anything else takes the generic path
     [[maybe_unused]] auto lean_ok = [&]() {
-        if constexpr (!(EPI == EPI_STORE_T || EPI == EPI_GATE_T || EPI == EPI_ROPE_T) || VAR == 31 || VAR == 32 || VAR == 15) return false;
+        if constexpr (!(EPI == EPI_STORE_T || EPI == EPI_GATE_T || EPI == EPI_ROPE_T)) return false;
         bool ok = m0 + BM <= p.M && n0 + BN <= p.N && (p.ldo & 7) == 0 && p.bias != nullptr && p.act != ACT_GELU_ERF;
         if constexpr (EPI == EPI_GATE_T) ok = ok && p.gate_bstride == 0 && (!p.rowmask || p.rowbits);
         if constexpr (EPI == EPI_ROPE_T) ok = ok && p.rows_per_batch >= WM;
@@ -496,10 +418,6 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
     };
 
     if constexpr (PERSIST) {
-        if (p.skew_ticks > 0 && ((blockIdx.x >> 3) & 1)) {  // experiment: half of the workgroups of every XCD start late
-            const unsigned long long t0 = wall_clock64();
-            while (wall_clock64() - t0 < (unsigned long long)p.skew_ticks) __builtin_amdgcn_s_sleep(32);
-        }
         // ---- persistent staggered ring: the ring never drains between tiles.  Global stage g = (tile ordinal) * nk + kt lives in
         //      slot g % NSTAGE; the DMA front runs D stages ahead and crosses into the next tile's operands, so a tile's first
         //      K-steps are already in LDS when the previous tile's epilogue ends.  The two wave groups re-synchronise around
@@ -604,112 +522,46 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
         }
         return;
     }
-    constexpr bool HS = (VAR == 20 || VAR == 21);  // half-slab ring (21: timing-only, without the MFMAs)
-    constexpr int D = HS ? 3 : NSTAGE - 1;  // ring units issued ahead of the one being consumed
-    if constexpr (VAR == 2) {  // nk even and >= 4 (launcher)
-        issue_pair(0);
-        issue_pair(2);
-    } else {
+    constexpr int D = NSTAGE - 1;  // K-steps issued ahead of the one being consumed
 #pragma unroll
-        for (int d = 0; d < D; ++d)
-            if (d < nk) issue(d);
-    }
+    for (int d = 0; d < D; ++d)
+        if (d < nk) issue(d);
     init_acc();
-    if constexpr (VAR == 2)
-        wait_pieces(2);  // pair (2, 3) may be in flight (and, harmlessly waited for, the last piece of K-step 1)
-    else if constexpr (HS)
-        wait_pieces(max(min(D - 1, nk - 1) - 1, 0));  // half-slabs 0 and 1 (K-step 0) have landed for this wave
-    else
-        wait_pieces(min(D - 1, nk - 1));  // K-step 0 has landed for this wave
-    __builtin_amdgcn_s_barrier();         // ... and for every wave
+    wait_pieces(min(D - 1, nk - 1));  // K-step 0 has landed for this wave
+    __builtin_amdgcn_s_barrier();     // ... and for every wave
 
-    if constexpr (VAR == 0 || VAR == 14) {
-        // (VAR 14: timing-only, this schedule without the MFMAs)
+    if constexpr (VAR == 0) {
         // ---- plain ring: every wave does {refill, fragment reads, MFMAs} per K-step, one barrier per K-step
-        const int abl = p.ablate;  // timing-only ablation bits (tools/narrow_ablate.py): 1 no MFMA, 2 no DMA refill, 4 fragments read once, 8 no barrier
         bf16x8 wf[NI], af[MI];
         for (int kt = 0; kt < nk; ++kt) {
-            if (!(abl & 2) && kt + D < nk) issue(kt + D);  // refills slot (kt-1) % NSTAGE: its readers passed the previous barrier
-            if (!(abl & 4) || kt == 0) read_frags(kt, wf, af);
-            if constexpr (VAR == 0) {
-                if (!(abl & 1)) mma(wf, af);
-            } else {
-#pragma unroll
-                for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(wf[i]));
-#pragma unroll
-                for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(af[j]));
-            }
+            if (kt + D < nk) issue(kt + D);  // refills slot (kt-1) % NSTAGE: its readers passed the previous barrier
+            read_frags(kt, wf, af);
+            mma(wf, af);
             if (kt + 1 < nk) {
                 wait_pieces(min(kt + D, nk - 1) - (kt + 1));
-                if (!(abl & 8)) __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
             }
-        }
-        if (abl) {
-#pragma unroll
-            for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(wf[i]));
-#pragma unroll
-            for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(af[j]));
         }
     } else {
         // ---- ring + staggered wave groups (the two waves that share a SIMD never run the same phase together):
         //   every wave alternates  P_k: {refill slot (k-1) % NSTAGE by DMA, ds_read the fragments of K-step k, counted vmcnt
         //   for K-step k+1}  |barrier|  C_k: {32 MFMAs}  |barrier| ...; waves 4-7 run one barrier interval behind waves 0-3,
         //   so in every interval one group feeds the matrix pipe while its SIMD partners do their LDS/DMA work.
-        // VAR >= 10: timing-only ablations (results are wrong by construction): 10 no DMA in the loop, 11 fragments read once, 12 no MFMA
         const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
         if (late) __builtin_amdgcn_s_barrier();
         bf16x8 wf[NI], af[MI];
         for (int kt = 0; kt < nk; ++kt) {
             // -- P_kt.  Slot (kt-1) % NSTAGE is free: both groups retired their reads of it (lgkmcnt(0) below) at least one barrier ago.
-            if constexpr (VAR == 3) {
-                if (kt + D < nk) {
-#pragma unroll
-                    for (int pc = 0; pc < PPW / 2; ++pc) issue_piece((kt + D) % NSTAGE, kt + D, pc);
-                }
-            } else if constexpr (VAR == 2) {
-                // odd K-step: pair (kt+3, kt+4) into the slots of K-steps kt-2 and kt-1
-                if ((kt & 1) && kt + 4 < nk) issue_pair(kt + 3);
-            } else {
-                if (VAR != 10 && kt + D < nk) issue(kt + D);
-            }
-            if (VAR != 11 || kt == 0) read_frags(kt, wf, af);
+            if (kt + D < nk) issue(kt + D);
+            read_frags(kt, wf, af);
             // my pieces of K-step kt+1 must have landed before the barrier that precedes anybody's P_{kt+1}
-            if constexpr (HS) {
-                // sub-step 2t+1 is followed by K-step t+1 = half-slabs kt+1 and kt+2; after an even sub-step nothing new is needed
-                if ((kt & 1) && kt + 1 < nk) wait_pieces(max(min(kt + D, nk - 1) - (kt + 2), 0));
-            } else if constexpr (VAR == 2) {
-                // whole pairs issued behind the pair that holds K-step kt+1 may stay in flight
-                const int last = min((kt & 1) ? kt + 4 : kt + 3, nk - 1);
-                wait_pieces(kt + 1 < nk ? ((last - ((kt + 1) | 1)) / 2) * 2 : 0);
-            } else {
-                wait_pieces(kt + 1 < nk ? min(kt + D, nk - 1) - (kt + 1) : 0);
-            }
+            wait_pieces(kt + 1 < nk ? min(kt + D, nk - 1) - (kt + 1) : 0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             // -- C_kt
             __builtin_amdgcn_s_setprio(1);
-            if constexpr (VAR == 3) {
-                // second half of the DMA pieces rides in the MFMA phase (balances the two barrier intervals)
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-#pragma unroll
-                    for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
-                    if (i == NI / 2 - 1 && kt + D < nk) {
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int pc = PPW / 2; pc < PPW; ++pc) issue_piece((kt + D) % NSTAGE, kt + D, pc);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            } else if constexpr (VAR != 12 && VAR != 13 && VAR != 21) {
-                mma(wf, af);
-            } else {
-#pragma unroll
-                for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(wf[i]));
-#pragma unroll
-                for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(af[j]));
-            }
+            mma(wf, af);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -720,11 +572,9 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
     epilogue();
 }
 
-int g_gemm_variant = 1;  // tuning knob (f5_tuning_set("gemm_variant", v)): 0 = plain ring, 1 = ring + staggered wave groups, 10-12 ablations
+int g_gemm_variant = 1;  // tuning knob (f5_tuning_set("gemm_variant", v)): 0 = plain ring everywhere, 1 = staggered wave groups (+ persistent grid)
 int g_gemm_group = 0;    // tuning knob ("gemm_group"): token tiles per L2 patch (0 = by shape, 1 = feature-tile-fastest order)
 int g_gemm_persist_grid = 0;  // tuning knob ("gemm_persist_grid"): workgroups of the persistent kernel (0 = one per CU of the device)
-int g_gemm_skew = 0;          // tuning knob ("gemm_skew"): see GemmParams::skew_ticks
-int g_gemm_fast_ablate = 0;   // tuning knob ("gemm_fast_ablate"): timing-only ablation bits of the plain-ring (narrow tile) loop
 int g_gemm_persist = 1;       // tuning knob ("gemm_persist"): 1 = whole-tile block linears run on the persistent grid
 static int persist_grid() {
     if (g_gemm_persist_grid > 0) return g_gemm_persist_grid;
@@ -738,16 +588,12 @@ static int persist_grid() {
     return cus;
 }
 int g_gemm_lean = 1;   // tuning knob ("gemm_lean"): 1 = lean epilogue on whole tiles, 0 = generic epilogue everywhere
-int g_gemm_nt = 0;     // tuning knob ("gemm_nt"): bit e = lean epilogue e (GemmEpi) uses non-temporal stores
 
 template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmParams& p0, hipStream_t stream) {
     GemmParams p = p0;
-    // L2 patch height: 8 token tiles per XCD patch; 16 for the 8-feature-tile (N = 2048) projection (tools/group_probe.py: FF1 985 -> 1 020 TFLOP/s)
+    // L2 patch height: 8 token tiles per XCD patch; 16 for the 8-feature-tile (N = 2048) projection (FF1 985 -> 1 020 TFLOP/s)
     p.tile_group = g_gemm_group > 0 ? g_gemm_group : (cdiv(p.N, BN) == 8 ? 16 : 8);
     p.lean_epi = g_gemm_lean;
-    p.ablate = g_gemm_fast_ablate;
-    p.skew_ticks = g_gemm_skew;
-    p.nt_store = g_gemm_nt >= 256 ? (g_gemm_nt >> 8) : ((g_gemm_nt >> EPI) & 1);  // >= 256: store flavour experiment (2 = sc0 sc1, 3 = sc0 sc1 nt) for every epilogue
     const int tiles_m = cdiv(p.M, 256), tiles_n = cdiv(p.N, BN);
     const int nblocks = tiles_m * tiles_n;
     dim3 grid(nblocks), block(512);
@@ -760,26 +606,7 @@ template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmPa
     if constexpr (BN == 256) {
         if (g_gemm_variant == 0)
             hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 0, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
-        else if (g_gemm_variant >= 10 && g_gemm_variant <= 17 && EPI == EPI_GATE_T) {
-            if (g_gemm_variant == 10) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 10, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
-            if (g_gemm_variant == 11) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 11, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
-            if (g_gemm_variant == 12) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 12, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
-            if (g_gemm_variant == 13) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 13, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
-            if (g_gemm_variant == 14) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 14, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
-            if (g_gemm_variant == 15) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 15, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
-            if (g_gemm_variant == 16) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 16, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
-            if (g_gemm_variant == 17) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI_GATE_T, 17, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
-        }
-        // (schedules 3 = split DMA issue and 20/21 = half-slab ring with whole-line pieces are kept in the kernel source as measured
-        //  alternatives but no longer instantiated: -4 % / 0 %)
-        else if (g_gemm_variant == 2 && MODE == GEMM_DENSE && EPI == EPI_GATE_T && p.K % 64 == 0 && p.K >= 128)  // paired K-step DMA (-3 %)
-            hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI_GATE_T, 2, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
-        else if ((g_gemm_variant >= 31 && g_gemm_variant <= 33) && MODE == GEMM_DENSE && EPI == EPI_GATE_T) {
-            const dim3 pg(nblocks < persist_grid() ? nblocks : persist_grid());
-            if (g_gemm_variant == 31) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI_GATE_T, 31, 5>), pg, block, 0, stream, p, tiles_n, nblocks);
-            if (g_gemm_variant == 32) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI_GATE_T, 32, 5>), pg, block, 0, stream, p, tiles_n, nblocks);
-            if (g_gemm_variant == 33) hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI_GATE_T, 33, 5>), pg, block, 0, stream, p, tiles_n, nblocks);
-        } else if ((g_gemm_variant == 30 || (g_gemm_variant == 1 && g_gemm_persist)) && persist_ok) {
+        else if (g_gemm_persist && persist_ok) {
             if constexpr (EPI == EPI_STORE_T || EPI == EPI_GATE_T || EPI == EPI_ROPE_T)
                 hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI, 30, 5>), dim3(nblocks < persist_grid() ? nblocks : persist_grid()), block,
                                    0, stream, p, tiles_n, nblocks);
@@ -811,7 +638,6 @@ bool gemm_fast_supported(const GemmParams& p, int precision, int mode, int epi) 
 }
 
 int launch_gemm_fast(const GemmParams& p, int mode, int epi, hipStream_t stream) {
-    if (g_gemm_variant == 1 && gemm_big_supported(p, mode, epi)) return launch_gemm_big(p, epi, stream);
     if (mode == GEMM_CONV31) {
         if (conv31_supported(p, F5_PREC_BF16, epi)) return launch_conv31(p, stream);
         if (epi == EPI_STORE_T) return launch_fast<64, 32, GEMM_CONV31, EPI_STORE_T>(p, stream);

@@ -1,4 +1,4 @@
-// gemm_tile.h -- device helpers shared by the tuned GEMM kernels (gemm_fast.hip, gemm_big.hip)
+// gemm_tile.h -- device helpers of the tuned GEMM kernel (gemm_fast.hip) and the halo-tile conv kernel (conv31.hip)
 #pragma once
 #include "gemm.h"
 #include <type_traits>

@@ -49,9 +49,12 @@ struct f5_model_s {
     float inv_freq[32];
 };
 
+extern int g_tuning_epoch;  // bumped by every f5_tuning_set: graphs captured under other knob values are dropped (ops.hip)
+
 struct GraphEntry {
     int B, N, nt, steps, method, cfg_on, mask_on;
     float cfg;
+    int epoch;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
 };
@@ -75,11 +78,27 @@ struct f5_plan_s {
     std::vector<float> mod_tv;  // evaluation times the AdaLN rows in `mod` were computed for (empty = stale); see f5_sample
     std::vector<GraphEntry> graphs;
     hipStream_t cap_stream = nullptr;  // capture happens on a private stream (the caller's may be the legacy null stream)
-    // in-situ timing of the dominant kernel (fused QKV GEMM): HIP event pairs around every launch of an eager sample()
+    // in-situ timing of the block kernels: HIP event pairs around every launch of an eager sample() (f5_plan_timing_*)
     bool timing = false;
     std::vector<hipEvent_t> ev;
+    std::vector<int> ev_site;  // call site of pair i (F5_SITE_*)
     size_t ev_used = 0;
+    double site_ms[F5_SITE_COUNT] = {0};
+    int site_n[F5_SITE_COUNT] = {0};
 };
+
+// runs `launch` (a kernel launcher returning a status) between an event pair tagged with `site` while timing is on
+template <typename F> static int timed(f5_plan_s* p, int site, hipStream_t st, F&& launch) {
+    if (p->timing && p->ev_used + 2 <= p->ev.size()) {
+        (void)hipEventRecord(p->ev[p->ev_used], st);
+        const int rc = launch();
+        (void)hipEventRecord(p->ev[p->ev_used + 1], st);
+        p->ev_site[p->ev_used / 2] = site;
+        p->ev_used += 2;
+        return rc;
+    }
+    return launch();
+}
 
 // ----------------------------------------------------------------------------- model
 static void add_slot(SlotMap& s, const std::string& name, std::vector<int64_t> shape) { s[name].shape = std::move(shape); }
@@ -97,6 +116,7 @@ extern "C" int f5_model_create(const f5_dit_config* c, f5_model_t* out) {
     if (c->text_dim <= 0 || c->text_dim % 32 != 0 || c->text_dim > 1024) return f5_fail(F5_EINVAL, "text_dim=%d must be a multiple of 32", c->text_dim);
     if (c->text_num_embeds <= 0 || c->conv_layers < 0) return f5_fail(F5_EINVAL, "bad text config");
     if (c->precision != F5_PREC_BF16 && c->precision != F5_PREC_FP32) return f5_fail(F5_EINVAL, "bad precision");
+    if (c->rope_layout != F5_ROPE_ADJACENT && c->rope_layout != F5_ROPE_HALF_SPLIT) return f5_fail(F5_EINVAL, "bad rope_layout");
     f5_model_s* m = new f5_model_s();
     m->cfg = *c;
     const int64_t D = c->dim, td = c->text_dim, inner = (int64_t)c->heads * 64, ff = c->ff_inner, mel = c->mel_dim;
@@ -291,6 +311,24 @@ extern "C" int f5_model_finalize(f5_model_t m) {
             memcpy(&w[(size_t)j * inner * D], H(m, p + "attn." + nm[j] + ".weight").data(), inner * D * sizeof(float));
             memcpy(&bias[(size_t)j * inner], H(m, p + "attn." + nm[j] + ".bias").data(), inner * sizeof(float));
         }
+        if (c.rope_layout == F5_ROPE_HALF_SPLIT) {
+            // The kernels rotate ADJACENT feature pairs.  The half-split form turns (j, j + 32) with frequency j; QK^T is invariant under
+            // one permutation of the 64 features of a head applied to q and k alike, so the q/k output rows are re-ordered once here
+            // (new 2j <- old j, new 2j+1 <- old j + 32) and the adjacent-pair rotation then IS the half-split rotation.  v is untouched.
+            std::vector<float> row(D);
+            for (int part = 0; part < 2; ++part)
+                for (int hd = 0; hd < m->rope_heads; ++hd) {
+                    float* wb = &w[((size_t)part * inner + (size_t)hd * 64) * D];
+                    float* bb = &bias[(size_t)part * inner + (size_t)hd * 64];
+                    std::vector<float> wo(wb, wb + 64 * D), bo(bb, bb + 64);
+                    for (int j = 0; j < 32; ++j) {
+                        memcpy(wb + (size_t)(2 * j) * D, &wo[(size_t)j * D], D * sizeof(float));
+                        memcpy(wb + (size_t)(2 * j + 1) * D, &wo[(size_t)(j + 32) * D], D * sizeof(float));
+                        bb[2 * j] = bo[j];
+                        bb[2 * j + 1] = bo[j + 32];
+                    }
+                }
+        }
         F5_TRY(f5_upload_t(A, P, w.data(), w.size(), &b.w_qkv));
         F5_TRY(f5_upload_f32(A, bias.data(), bias.size(), &b.b_qkv));
         F5_TRY(f5_upload_t(A, P, H(m, p + "attn.to_out.0.weight").data(), D * inner, &b.w_o));
@@ -429,6 +467,7 @@ extern "C" int f5_plan_timing_begin(f5_plan_t p, int max_launches) {
     if (!p || max_launches <= 0) return f5_fail(F5_EINVAL, "bad argument");
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     p->ev.assign((size_t)max_launches * 2, nullptr);
+    p->ev_site.assign((size_t)max_launches, 0);
     for (auto& e : p->ev) F5_HIP(hipEventCreate(&e));
     p->ev_used = 0;
     p->timing = true;
@@ -439,20 +478,29 @@ extern "C" int f5_plan_timing_end(f5_plan_t p, float* avg_ms, int* launches, f5_
     if (!p || !avg_ms || !launches) return f5_fail(F5_EINVAL, "null argument");
     p->timing = false;
     F5_HIP(hipStreamSynchronize((hipStream_t)stream));
-    double sum = 0.0;
-    int n = 0;
+    for (int s = 0; s < F5_SITE_COUNT; ++s) {
+        p->site_ms[s] = 0.0;
+        p->site_n[s] = 0;
+    }
     for (size_t i = 0; i + 1 < p->ev_used; i += 2) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]) == hipSuccess) {
-            sum += ms;
-            ++n;
+            p->site_ms[p->ev_site[i / 2]] += ms;
+            ++p->site_n[p->ev_site[i / 2]];
         }
     }
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     p->ev.clear();
     p->ev_used = 0;
-    *avg_ms = n ? (float)(sum / n) : 0.f;
-    *launches = n;
+    *avg_ms = p->site_n[F5_SITE_QKV] ? (float)(p->site_ms[F5_SITE_QKV] / p->site_n[F5_SITE_QKV]) : 0.f;
+    *launches = p->site_n[F5_SITE_QKV];
+    return 0;
+}
+
+extern "C" int f5_plan_timing_site(f5_plan_t p, int site, float* avg_ms, int* launches) {
+    if (!p || !avg_ms || !launches || site < 0 || site >= F5_SITE_COUNT) return f5_fail(F5_EINVAL, "bad argument");
+    *avg_ms = p->site_n[site] ? (float)(p->site_ms[site] / p->site_n[site]) : 0.f;
+    *launches = p->site_n[site];
     return 0;
 }
 
@@ -564,7 +612,7 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
     g.A = p->xin; g.lda = MELP; g.W = m->w_x; g.ldw = MELP; g.M = rows; g.N = D; g.K = MELP;
     g.a_row_mod = xrows < rows ? xrows : 0;
     g.addend = p->base; g.ldadd = D; g.out_t = p->hT; g.ldo = D; g.out_f = p->xres; g.ldof = D;
-    F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_ADD2, st));
+    F5_TRY(timed(p, F5_SITE_INPUT, st, [&] { return run_gemm(p, g, GEMM_DENSE, EPI_ADD2, st); }));
     // x_res = h + mish(conv(mish(conv(h)))): the second conv only STORES its branch (activation dtype); every fp32 residual
     // add of the network is fused into the LayerNorm pass that follows it (coalesced streaming RMW, store-only GEMM epilogues)
     for (int li = 0; li < 2; ++li) {
@@ -572,7 +620,7 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         g.A = li == 0 ? p->hT : p->cT; g.lda = D; g.W = m->w_conv[li]; g.M = rows; g.N = D; g.K = 31 * m->conv_win;
         g.bias = m->b_conv[li]; g.act = ACT_MISH; g.rows_per_batch = N; g.conv_cg = m->conv_cg; g.conv_win = m->conv_win;
         g.out_t = li == 0 ? p->cT : p->yT; g.ldo = D;
-        F5_TRY(run_gemm(p, g, GEMM_CONV31, li == 0 ? EPI_STORE_T : EPI_GATE_T, st));
+        F5_TRY(timed(p, F5_SITE_CONV, st, [&] { return run_gemm(p, g, GEMM_CONV31, li == 0 ? EPI_STORE_T : EPI_GATE_T, st); }));
     }
 
     const bool defer = p->taps.empty() && g_ln_defer;
@@ -583,7 +631,9 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         // x += (conv branch | previous block's gated FF output); n1 = LN(x) * (1 + scale_msa) + shift_msa
         // With no stage tap set, the fp32 residual stream is written once per block: this pass normalises x + y without storing it,
         // the second LayerNorm of the block repeats the add (same operands, same order: bit-identical) and stores x + y + y_attn.
-        F5_TRY(launch_layernorm_add2(P, p->xres, D, rows, D, p->yT, D, nullptr, defer ? 2 : 1, ml + D, ml, mod_bstride, N, 1, p->hT, D, st));
+        F5_TRY(timed(p, F5_SITE_LN1, st, [&] {
+            return launch_layernorm_add2(P, p->xres, D, rows, D, p->yT, D, nullptr, defer ? 2 : 1, ml + D, ml, mod_bstride, N, 1, p->hT, D, st);
+        }));
         if (l == 0) F5_TRY(tap_f32(p, "input_embed", p->xres, D, rows, D, st));
         if (l > 0) F5_TRY(tap_f32(p, "blk" + std::to_string(l - 1) + ".out", p->xres, D, rows, D, st));
         F5_TRY(tap_t(p, tn + ".n1", p->hT, D, rows, D, st));
@@ -591,18 +641,11 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         g.A = p->hT; g.lda = D; g.W = b.w_qkv; g.ldw = D; g.M = rows; g.N = 3 * inner; g.K = D;
         g.bias = b.b_qkv; g.out_t = p->qkv; g.ldo = 3 * inner; g.rows_per_batch = N;
         g.rope = p->rope; g.rope_inner = inner; g.rope_heads = m->rope_heads;
-        if (p->timing && p->ev_used + 2 <= p->ev.size()) {
-            (void)hipEventRecord(p->ev[p->ev_used], st);
-            F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_ROPE_T, st));
-            (void)hipEventRecord(p->ev[p->ev_used + 1], st);
-            p->ev_used += 2;
-        } else {
-            F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_ROPE_T, st));
-        }
+        F5_TRY(timed(p, F5_SITE_QKV, st, [&] { return run_gemm(p, g, GEMM_DENSE, EPI_ROPE_T, st); }));
         {
             int kind = 0;
             if (p->attn_kernel != 0 && attention_fast_supported(P, N, c.heads)) kind = 1;
-            F5_TRY(launch_attention(P, kind, nb, N, c.heads, p->qkv, 3 * inner, mask, p->cT, inner, st));
+            F5_TRY(timed(p, F5_SITE_ATTN, st, [&] { return launch_attention(P, kind, nb, N, c.heads, p->qkv, 3 * inner, mask, p->cT, inner, st); }));
         }
         if (float* d = tap_dst(p, tn + ".attn")) {  // Attention module output before gating (extra GEMM, debug only)
             g = gp_zero();
@@ -616,19 +659,21 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         g.bias = b.b_o; g.out_t = defer ? p->yA : p->yT; g.ldo = D; g.gate = ml + 2 * D; g.gate_bstride = mod_bstride; g.rows_per_batch = N;
         g.rowmask = mask;
         g.rowbits = (mask && mask == p->rowbits_src) ? p->rowbits : nullptr;
-        F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_GATE_T, st));
+        F5_TRY(timed(p, F5_SITE_OUT, st, [&] { return run_gemm(p, g, GEMM_DENSE, EPI_GATE_T, st); }));
         // x += y; n2 = LN(x) * (1 + scale_mlp) + shift_mlp
-        F5_TRY(launch_layernorm_add2(P, p->xres, D, rows, D, p->yT, D, defer ? p->yA : nullptr, defer ? 3 : 1, ml + 4 * D, ml + 3 * D, mod_bstride, N, 1,
-                                     p->hT, D, st));
+        F5_TRY(timed(p, F5_SITE_LN2, st, [&] {
+            return launch_layernorm_add2(P, p->xres, D, rows, D, p->yT, D, defer ? p->yA : nullptr, defer ? 3 : 1, ml + 4 * D, ml + 3 * D, mod_bstride, N, 1,
+                                         p->hT, D, st);
+        }));
         g = gp_zero();
         g.A = p->hT; g.lda = D; g.W = b.w_ff1; g.ldw = D; g.M = rows; g.N = ff; g.K = D;
         g.bias = b.b_ff1; g.act = ACT_GELU_TANH; g.out_t = p->ffh; g.ldo = ff;
-        F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_STORE_T, st));
+        F5_TRY(timed(p, F5_SITE_FF1, st, [&] { return run_gemm(p, g, GEMM_DENSE, EPI_STORE_T, st); }));
         // y = gate_mlp * ff(n2)  (modules.py:639)
         g = gp_zero();
         g.A = p->ffh; g.lda = ff; g.W = b.w_ff2; g.ldw = ff; g.M = rows; g.N = D; g.K = ff;
         g.bias = b.b_ff2; g.out_t = p->yT; g.ldo = D; g.gate = ml + 5 * D; g.gate_bstride = mod_bstride; g.rows_per_batch = N;
-        F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_GATE_T, st));
+        F5_TRY(timed(p, F5_SITE_FF2, st, [&] { return run_gemm(p, g, GEMM_DENSE, EPI_GATE_T, st); }));
     }
     const float* mf = modp + (size_t)c.depth * 6 * D;  // final AdaLN: (scale, shift) (modules.py:333)
     F5_TRY(launch_layernorm_add(P, p->xres, D, rows, D, p->yT, D, mf, mf + D, mod_bstride, N, 1, p->hT, D, st));
@@ -764,12 +809,21 @@ extern "C" int f5_sample(f5_plan_t p, int B, int N, const float* cond, const int
     SampleArgs a{B, N, nt_eff, steps, ode_method, cfg_strength >= 1e-5f ? 1 : 0, durations ? 1 : 0, cfg_strength};  // cfm.py:167
     if (use_graph && p->taps.empty() && !p->timing) {
         GraphEntry* ge = nullptr;
+        for (size_t i = 0; i < p->graphs.size();) {  // a tuning knob changed since the capture: the graph baked the old kernel choice
+            if (p->graphs[i].epoch != g_tuning_epoch) {
+                (void)hipGraphExecDestroy(p->graphs[i].exec);
+                (void)hipGraphDestroy(p->graphs[i].graph);
+                p->graphs.erase(p->graphs.begin() + i);
+            } else {
+                ++i;
+            }
+        }
         for (auto& g : p->graphs)
             if (g.B == B && g.N == N && g.nt == a.nt && g.steps == steps && g.method == ode_method && g.cfg_on == a.cfg_on &&
                 g.mask_on == a.mask_on && g.cfg == a.cfg)
                 ge = &g;
         if (!ge) {
-            GraphEntry g{B, N, a.nt, steps, ode_method, a.cfg_on, a.mask_on, a.cfg};
+            GraphEntry g{B, N, a.nt, steps, ode_method, a.cfg_on, a.mask_on, a.cfg, g_tuning_epoch};
             if (!p->cap_stream) F5_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
             F5_HIP(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeRelaxed));
             int rc = sample_body(p, a, p->cap_stream);

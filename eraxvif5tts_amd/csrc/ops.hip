@@ -351,23 +351,17 @@ extern "C" int f5_bench_mfma_rate(int random_operands, float* tflops, f5_stream_
     return sync_and_release(a, st, rc);
 }
 
-extern int g_gemm_variant, g_gemm_group, g_gemm_persist_grid, g_gemm_persist, g_gemm_fast_ablate, g_gemm_skew, g_gemm_lean, g_gemm_nt, g_gemm_big, g_gemm_big_ablate, g_ln_defer, g_conv31, g_attn_occ, g_attn_ablate, g_attn_variant;
+extern int g_gemm_variant, g_gemm_group, g_gemm_persist_grid, g_gemm_persist, g_gemm_lean, g_ln_defer, g_conv31, g_attn_variant;
+int g_tuning_epoch = 0;
 extern "C" int f5_tuning_set(const char* key, int value) {
     if (!key) return f5_fail(F5_EINVAL, "null key");
+    ++g_tuning_epoch;  // hipGraphs captured by plans under the previous knob values are dropped at their next use (model.hip)
     if (strcmp(key, "gemm_variant") == 0) {
         g_gemm_variant = value;
         return 0;
     }
-    if (strcmp(key, "attn_occ") == 0) {
-        g_attn_occ = value;
-        return 0;
-    }
     if (strcmp(key, "attn_variant") == 0) {
         g_attn_variant = value;
-        return 0;
-    }
-    if (strcmp(key, "attn_ablate") == 0) {
-        g_attn_ablate = value;
         return 0;
     }
     if (strcmp(key, "gemm_group") == 0) {
@@ -386,28 +380,8 @@ extern "C" int f5_tuning_set(const char* key, int value) {
         g_ln_defer = value != 0;
         return 0;
     }
-    if (strcmp(key, "gemm_big_ablate") == 0) {
-        g_gemm_big_ablate = value;
-        return 0;
-    }
-    if (strcmp(key, "gemm_big") == 0) {
-        g_gemm_big = value;
-        return 0;
-    }
-    if (strcmp(key, "gemm_nt") == 0) {
-        g_gemm_nt = value;
-        return 0;
-    }
     if (strcmp(key, "gemm_lean") == 0) {
         g_gemm_lean = value != 0;
-        return 0;
-    }
-    if (strcmp(key, "gemm_fast_ablate") == 0) {
-        g_gemm_fast_ablate = value;
-        return 0;
-    }
-    if (strcmp(key, "gemm_skew") == 0) {
-        g_gemm_skew = value;
         return 0;
     }
     if (strcmp(key, "gemm_persist") == 0) {
@@ -419,7 +393,6 @@ extern "C" int f5_tuning_set(const char* key, int value) {
         g_gemm_persist_grid = value;
         return 0;
     }
-    if (strcmp(key, "gemm_stages") == 0) return 0;  // retired knob (the 256-wide tile always uses the 5-slot ring); accepted for old probe scripts
     if (strcmp(key, "bench_pad_a") == 0) {
         g_bench_pad_a = value;
         return 0;

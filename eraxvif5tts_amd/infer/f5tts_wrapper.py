@@ -10,8 +10,8 @@ Differences forced by the offline, ROCm-only image (each raises instead of silen
   * no Whisper ASR is initialised (reference :100 downloads openai/whisper-large-v3-turbo): ``ref_text`` must be given;
   * checkpoints and the Vocos weights must be local files (reference :125 / utils_infer.py:110-112 fetch from the hub);
   * ``device`` must be a ROCm GPU: the backbone has no CPU path.
-The optional conv duration predictor (:381-406) is a "next" row of the scope table and is reported as absent, which is the
-reference's own fallback branch (:166-168).
+The optional conv duration predictor (:381-406) runs on the HIP path (``model/duration_predictor.py`` over ``f5_duration_predict``)
+when the loaded model carries one; otherwise the reference's own fallback branch is taken (:166-168).
 """
 from __future__ import annotations
 
@@ -136,9 +136,6 @@ class F5TTSWrapper:
 
     def _remove_silence_edges(self, audio, silence_threshold=-42):
         return _audio.remove_silence_edges(audio, silence_threshold)
-
-    def calculate_duration_with_predictor(self, text_tokens, text_lengths, local_speed=1.0):
-        raise NotImplementedError("the optional duration predictor is not part of this build (scope table row f.2)")
 
     def calculate_duration_with_predictor(self, text_tokens, text_lengths, local_speed=1.0):
         """Reference :381-406, op for op: token mask from the lengths, ``model.duration_predictor(tokens, mask)`` -> [b, 1, nt]

@@ -69,7 +69,7 @@ def _register(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer=False):
 class DiT(nn.Module):
     def __init__(self, *, dim, depth=8, heads=8, dim_head=64, dropout=0.1, ff_mult=4, mel_dim=100, text_num_embeds=256,
                  text_dim=None, text_mask_padding=True, qk_norm=None, conv_layers=0, pe_attn_head=None,
-                 long_skip_connection=False, checkpoint_activations=False, precision=None):
+                 long_skip_connection=False, checkpoint_activations=False, precision=None, rope_layout=None):
         super().__init__()
         if text_dim is None:
             text_dim = mel_dim
@@ -84,6 +84,10 @@ class DiT(nn.Module):
         self.checkpoint_activations = checkpoint_activations  # training-only knob; accepted and ignored
         prec = precision or os.environ.get("F5HIP_PRECISION", "bf16")
         self.precision = {"bf16": _lib.F5_PREC_BF16, "fp32": _lib.F5_PREC_FP32}[prec]
+        # x_transformers (dit.py:16,134) is not vendored in the reference tree: "adjacent" rotates feature pairs (2j, 2j+1), the form the
+        # pinned >= 1.31 releases publish (default); "half_split" rotates (j, j+32).  ONE switch, also settable as F5HIP_ROPE_LAYOUT.
+        layout = rope_layout or os.environ.get("F5HIP_ROPE_LAYOUT", "adjacent")
+        self.rope_layout = {"adjacent": _lib.F5_ROPE_ADJACENT, "half_split": _lib.F5_ROPE_HALF_SPLIT}[layout]
 
         for name, shape, init in _param_spec(dim, depth, heads, dim_head, self.ff_inner, mel_dim, text_num_embeds, text_dim, conv_layers):
             t = torch.empty(shape)
@@ -105,6 +109,7 @@ class DiT(nn.Module):
 
         self.text_cond, self.text_uncond = None, None  # text cache (reference dit.py:131)
         self._native = None
+        self._native_versions = None
         self._plans = []
         self._seen_shapes = {}
         self.register_load_state_dict_post_hook(lambda module, _keys: module._drop_native())
@@ -126,8 +131,20 @@ class DiT(nn.Module):
         except Exception:  # noqa: BLE001
             pass
 
+    def _param_versions(self):
+        return tuple(p._version for p in self.parameters())
+
+    def refresh_native(self):
+        """Drop the HBM weight snapshot, every plan and the cached AdaLN rows: the next forward()/sample() re-uploads the CURRENT
+        parameter values.  load_state_dict() does this by itself, and so does native() when a parameter was modified in place
+        (p.copy_, EMA swap: torch bumps the tensor's version counter); call it explicitly after edits torch cannot see (.data)."""
+        self._drop_native()
+
     def native(self):
-        """Upload the current parameter values to HBM in the kernels' layouts (once; redone after load_state_dict)."""
+        """Upload the current parameter values to HBM in the kernels' layouts (once; redone after load_state_dict or an in-place
+        parameter update)."""
+        if self._native is not None and self._native_versions != self._param_versions():
+            self._drop_native()
         if self._native is not None:
             return self._native
         _lib.require_gpu()
@@ -135,7 +152,8 @@ class DiT(nn.Module):
         cfg = _lib.DitConfig(dim=self.dim, depth=self.depth, heads=self.heads, dim_head=self.dim_head, ff_inner=self.ff_inner,
                              mel_dim=self.mel_dim, text_num_embeds=self.text_num_embeds, text_dim=self.text_dim,
                              conv_layers=self.conv_layers, text_mask_padding=int(self.text_mask_padding),
-                             pe_attn_head=self.pe_attn_head or 0, qk_norm=0, long_skip=0, precision=self.precision)
+                             pe_attn_head=self.pe_attn_head or 0, qk_norm=0, long_skip=0, precision=self.precision,
+                             rope_layout=self.rope_layout)
         h = C.c_void_p()
         _lib.check(lib.f5_model_create(C.byref(cfg), C.byref(h)), "model_create")
         try:
@@ -145,10 +163,12 @@ class DiT(nn.Module):
             lib.f5_model_destroy(h)
             raise
         self._native = h
+        self._native_versions = self._param_versions()
         return h
 
     def plan(self, batch, seq, evals=1):
         """Workspace for (batch, seq) problems; reused while it is large enough."""
+        self.native()  # (drops stale plans when a parameter changed in place)
         for (b, n, e), h in self._plans:
             if b >= batch and n >= seq and e >= evals:
                 return h

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define F5HIP_VERSION 100 /* 0.1.0 */
+#define F5HIP_VERSION 200 /* 0.2.0 */
 
 /* error codes */
 #define F5_OK 0
@@ -70,7 +70,13 @@ typedef struct f5_dit_config {
     int32_t qk_norm;           /* must be 0 (null in every shipped config) */
     int32_t long_skip;         /* must be 0 */
     int32_t precision;         /* F5_PREC_* */
+    int32_t rope_layout;       /* F5_ROPE_* : which feature pairs of a head one rotary frequency turns (x_transformers is not vendored
+                                * in the reference tree; the adjacent-pair form is the one the pinned >=1.31 releases publish) */
 } f5_dit_config;
+
+/* rotary layouts of the q/k head features (dim_head = 64, 32 frequencies), reference model/modules.py:452-461 via x_transformers */
+#define F5_ROPE_ADJACENT 0  /* frequency j turns features (2j, 2j+1): rotate_half on '... (d r) -> ... d r', r = 2 (default) */
+#define F5_ROPE_HALF_SPLIT 1 /* frequency j turns features (j, j+32): rotate_half on the two halves of the head (GPT-NeoX form) */
 
 const char* f5_last_error(void);
 int f5_version(void);
@@ -127,6 +133,19 @@ int f5_plan_set_tap(f5_plan_t p, const char* stage, float* dst);
  * returns the mean device time per launch.  Used by bench.py for roofline.achieved. */
 int f5_plan_timing_begin(f5_plan_t p, int max_launches);
 int f5_plan_timing_end(f5_plan_t p, float* avg_ms, int* launches, f5_stream_t stream);
+/* the same measurement for every kernel of a DiT evaluation: after f5_plan_timing_end, mean device time per launch of call site
+ * `site` (max_launches of f5_plan_timing_begin counts event pairs over ALL sites: 6 per block + 3 per evaluation). */
+#define F5_SITE_QKV 0   /* fused QKV projection + RoPE            modules.py:452-461 */
+#define F5_SITE_ATTN 1  /* scaled-dot-product attention           modules.py:483-497 */
+#define F5_SITE_OUT 2   /* attention out-projection x gate_msa    modules.py:499-501,635 */
+#define F5_SITE_FF1 3   /* FeedForward first linear + GELU(tanh)  modules.py:258-264 */
+#define F5_SITE_FF2 4   /* FeedForward second linear x gate_mlp   modules.py:639 */
+#define F5_SITE_LN1 5   /* residual add + AdaLN before attention  modules.py:301-317,632 */
+#define F5_SITE_LN2 6   /* residual add + AdaLN before the FF     modules.py:637-638 */
+#define F5_SITE_CONV 7  /* grouped Conv1d(k=31) + Mish (x2)       modules.py:167-190 */
+#define F5_SITE_INPUT 8 /* input projection of the noisy mel      dit.py:88-96 */
+#define F5_SITE_COUNT 9
+int f5_plan_timing_site(f5_plan_t p, int site, float* avg_ms, int* launches);
 /* kernel selection for A/B runs: key "gemm_kernel" / "attn_kernel"; value 0 = reference tile kernels, 1 or -1 = tuned
  * kernels wherever they support the problem (default).  Drops any captured graphs. */
 int f5_plan_set_option(f5_plan_t p, const char* key, int value);

@@ -149,9 +149,16 @@ def rope_angles(seq_len, dim_head=64, base=10000.0):
     return torch.outer(torch.arange(seq_len).float(), inv)  # [n, dim_head/2]
 
 
-def apply_rope(t, ang):
-    """x_transformers apply_rotary_pos_emb on [b, h, n, d]: adjacent pairs (x0,x1)->(x0 c - x1 s, x1 c + x0 s)."""
+def apply_rope(t, ang, half_split=False):
+    """x_transformers apply_rotary_pos_emb on [b, h, n, d]: adjacent pairs (x0,x1)->(x0 c - x1 s, x1 c + x0 s).
+    ``half_split=True`` is the other published rotary form (freqs = cat(freqs, freqs), rotate_half on the two halves of the head:
+    frequency j turns features (j, j + d/2)); x_transformers is not vendored in the reference tree, so both are kept behind ONE switch
+    (cfg["rope_layout"] == "half_split"; the adjacent form is what the pinned >= 1.31 releases compute)."""
     c, s = ang.cos()[None, None], ang.sin()[None, None]
+    if half_split:
+        d2 = t.shape[-1] // 2
+        x0, x1 = t[..., :d2].float(), t[..., d2:].float()
+        return torch.cat([x0 * c - x1 * s, x1 * c + x0 * s], dim=-1).to(t.dtype)
     x0, x1 = t[..., 0::2].float(), t[..., 1::2].float()
     out = torch.stack([x0 * c - x1 * s, x1 * c + x0 * s], dim=-1).flatten(-2)
     return out.to(t.dtype)
@@ -167,8 +174,9 @@ def attention(W, pre, cfg, x, mask, ang):
     v = _lin(x, W[pre + "to_v.weight"], W[pre + "to_v.bias"]).view(b, n, h, dh).transpose(1, 2)
     pn = cfg.get("pe_attn_head", None)
     pn = h if pn is None else pn
-    q = torch.cat([apply_rope(q[:, :pn], ang), q[:, pn:]], dim=1)
-    k = torch.cat([apply_rope(k[:, :pn], ang), k[:, pn:]], dim=1)
+    hs = cfg.get("rope_layout", "adjacent") == "half_split"
+    q = torch.cat([apply_rope(q[:, :pn], ang, hs), q[:, pn:]], dim=1)
+    k = torch.cat([apply_rope(k[:, :pn], ang, hs), k[:, pn:]], dim=1)
     s = torch.einsum("bhid,bhjd->bhij", q, k) / math.sqrt(dh)
     if mask is not None:
         s = s.masked_fill(~mask[:, None, None, :], float("-inf"))

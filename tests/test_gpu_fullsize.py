@@ -170,3 +170,73 @@ def test_sampler_is_run_to_run_deterministic():
             ref = out.clone()
         assert torch.equal(out, ref)
     assert torch.isfinite(ref).all()
+
+
+# ----------------------------------------------------------------------------- C4: long-form, seq_len 4096 (the reference's hard cap, cfm.py:93,135), batch 8
+def test_c4_attention_properties():
+    """B x H = 8 x 16 heads of 4096 x 64 (C4) on the kernel the launcher picks for that length: (1) V = 1 -> output = 1 up to the bf16
+    rounding of P; (2) keys behind the padding mask have no influence at all; (3) sampled (batch, head) pairs against the fp64 softmax."""
+    import gpu_helpers as G
+    from test_gpu_ops import _attn_ref
+    B, N, H = 8, 4096, 16
+    g = torch.Generator().manual_seed(2)
+    qkv = G.bf16_round(torch.randn(B, N, 3, H, 64, generator=g) * 1.5)
+    ones = qkv.clone()
+    ones[:, :, 2] = 1.0
+    out = G.op_attention(P_BF16, 1, ones, None)
+    assert torch.isfinite(out).all() and (out - 1.0).abs().max() < 8e-3
+    del ones
+    lens = torch.randint(N // 2, N + 1, (B,), generator=g)
+    lens[0] = N
+    mask = torch.arange(N)[None, :] < lens[:, None]
+    a = G.op_attention(P_BF16, 1, qkv, mask)
+    poisoned = qkv.clone()
+    junk = G.bf16_round(torch.randn(B, N, 2, H, 64, generator=g) * 50)
+    poisoned[:, :, 1:][~mask] = junk[~mask]
+    del junk
+    b = G.op_attention(P_BF16, 1, poisoned, mask)
+    assert torch.equal(a[mask], b[mask])
+    del poisoned, b
+    for bi, hi in ((0, 0), (3, 7), (7, 15)):
+        sub = qkv[bi:bi + 1, :, :, hi:hi + 1]
+        ref = _attn_ref(sub, mask[bi:bi + 1])
+        got = a[bi:bi + 1, :, hi * 64:(hi + 1) * 64]
+        v = mask[bi:bi + 1]
+        assert rel_l2(got[v], ref[v]) < 6e-3, (bi, hi)
+
+
+def test_c4_long_form_sampler_bf16_vs_fp32_mode():
+    """C4 shape through CFM.sample: F5TTS_Base (22 blocks), batch 8 x seq_len 4096 (65 536 token rows with CFG), sway sampling, NFE 2,
+    ragged durations (key-padding mask live).  The bf16 production path -- long-sequence attention schedule, persistent GEMM grid, hipGraph --
+    against the exact-fp32 parity mode of the same library on the first two utterances (rows are independent, see the C2 test above).
+    Stated tolerance: rel-L2 <= 2e-2 on the generated frames."""
+    import bench
+    from eraxvif5tts_amd.model import CFM, DiT
+    B, N = 8, 4096
+    cond, text, lens, dur = bench.synth_batch(B, N, "cuda", seed=21)
+    g = torch.Generator().manual_seed(22)
+    dur = dur - torch.randint(0, 900, (B,), generator=g).cuda()
+    dur[0] = N
+    y0 = torch.randn(B, N, 100, generator=g)
+    y0 = y0 * (torch.arange(N)[None, :, None] < dur.cpu()[:, None, None])
+    kw = dict(steps=2, cfg_strength=2.0, sway_sampling_coef=-1.0, return_trajectory=False)
+    outs = {}
+    for prec, nb in (("bf16", B), ("fp32", 2)):
+        torch.manual_seed(77)  # same default init for both precisions
+        model = bench.synth_weights(DiT(**bench.BASE_ARCH, text_num_embeds=bench.VOCAB, mel_dim=100, precision=prec), seed=0)
+        cfm = CFM(transformer=model, mel_spec_kwargs={"mel_spec_type": "vocos"}).cuda()
+        out, _ = cfm.sample(cond=cond[:nb], text=text[:nb], duration=dur[:nb], lens=lens[:nb], y0=y0[:nb], **kw)
+        if prec == "bf16":
+            again, _ = cfm.sample(cond=cond, text=text, duration=dur, lens=lens, y0=y0, **kw)
+            assert torch.equal(out, again)  # graph replay / determinism at the long-form shape
+        outs[prec] = out.cpu()
+        del cfm, model
+        torch.cuda.empty_cache()
+    n_ref = cond.shape[1]
+    assert torch.isfinite(outs["bf16"]).all()
+    assert torch.equal(outs["bf16"][:, :n_ref], cond.cpu())  # prompt frames come back verbatim (cfm.py:200-202)
+    d = [int(x) for x in dur.cpu()]
+    gen = lambda t: torch.cat([t[i, n_ref:d[i]] for i in range(2)])
+    err = rel_l2(gen(outs["bf16"]), gen(outs["fp32"]))
+    print(f"C4 bf16 vs fp32 mode, 22 blocks x 2 steps, N = 4096: rel-L2 {err:.3e}")
+    assert err < 2e-2

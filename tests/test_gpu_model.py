@@ -168,3 +168,29 @@ def test_duration_predictor_larger_shapes_vs_oracle():
     ref = cpu_ref.duration_predictor({k: v.detach() for k, v in net.state_dict().items()}, tokens, mask)
     out = net.cuda()(tokens.cuda(), mask.cuda()).cpu()
     assert rel_l2(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("pe_heads", [1, None])
+def test_rope_layout_switch_half_split(prec, pe_heads):
+    """x_transformers is not vendored, so the rotary pairing sits behind ONE switch (f5_dit_config.rope_layout / DiT(rope_layout=),
+    oracle cfg["rope_layout"]).  The half-split form (frequency j turns features j and j+32) on the HIP path against the oracle with
+    the same switch; and it must differ from the default adjacent-pair form (otherwise the switch would be dead)."""
+    import gpu_helpers as G
+    arch = dict(dim=128, depth=2, heads=2, ff_mult=2, text_dim=64, conv_layers=1, pe_attn_head=pe_heads, text_mask_padding=False)
+    V = 40
+    W = cpu_ref.random_dit_weights(arch, V, seed=31)
+    g = torch.Generator().manual_seed(32)
+    B, N = 2, 70
+    x, cond = torch.randn(B, N, 100, generator=g), torch.randn(B, N, 100, generator=g)
+    text = torch.randint(0, V, (B, 20), generator=g)
+    t = torch.tensor([0.3, 0.7])
+    dur = torch.tensor([N, N - 9])
+    mask = cpu_ref.lens_to_mask(dur)
+    ref = {lay: cpu_ref.dit_forward(W, {**arch, "rope_layout": lay}, x, cond, text, t, False, False, mask=mask) for lay in ("adjacent", "half_split")}
+    assert rel_l2(ref["half_split"], ref["adjacent"]) > 1e-2
+    for lay in ("adjacent", "half_split"):
+        m = G.make_dit({**arch, "rope_layout": lay}, V, W, prec)
+        out = m(x=x.cuda(), cond=cond.cuda(), text=text.cuda(), time=t.cuda(), mask=mask.cuda(), drop_audio_cond=False, drop_text=False, cache=False)
+        v = mask
+        assert rel_l2(out.cpu()[v], ref[lay][v]) < STAGE_TOL[prec], lay

@@ -228,6 +228,54 @@ def test_attention_tuned_kernel(B, N, H, masked, variant):
     assert (out[valid] - ref[valid]).abs().max() < 0.05
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2], ids=["default_by_length", "32_queries_per_wave", "64_queries_per_wave"])
+@pytest.mark.parametrize("N", [2048, 2050, 4000, 4096])
+@pytest.mark.parametrize("masked", [False, True], ids=["unmasked", "ragged_lens"])
+def test_attention_tuned_kernel_long_sequences(variant, N, masked):
+    """The long-form (C4) sequence lengths up to the reference's hard cap of 4096 frames (cfm.py:93,135): every attention schedule the
+    launcher can select there -- the default one included -- against the fp64 softmax, whole tiles (2048, 4096), ragged last tiles
+    (2050, 4000) and ragged per-utterance lengths behind the key-padding mask (modules.py:483-501)."""
+    import gpu_helpers as G
+    from eraxvif5tts_amd import _lib
+    B, H = (2, 2) if masked else (1, 2)
+    g = torch.Generator().manual_seed(N + 7 * variant)
+    qkv = G.bf16_round(torch.randn(B, N, 3, H, 64, generator=g) * 1.5)
+    mask = None
+    if masked:
+        lens = torch.tensor([N, N - 1037])
+        mask = torch.arange(N)[None, :] < lens[:, None]
+    ref = _attn_ref(qkv, mask)
+    _lib.check(_lib.load().f5_tuning_set(b"attn_variant", variant))
+    try:
+        out = G.op_attention(P_BF16, 1, qkv, mask)
+    finally:
+        _lib.check(_lib.load().f5_tuning_set(b"attn_variant", 0))
+    valid = slice(None) if mask is None else mask
+    assert torch.isfinite(out).all()
+    assert rel_l2(out[valid], ref[valid]) < 6e-3
+    assert (out[valid] - ref[valid]).abs().max() < 0.05
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_attention_long_sequence_spiked_scores(variant):
+    """online-softmax rescale path of every schedule at N = 4096: the running max jumps late (key 3900) and in the first tile."""
+    import gpu_helpers as G
+    from eraxvif5tts_amd import _lib
+    g = torch.Generator().manual_seed(11)
+    B, N, H = 1, 4096, 2
+    qkv = torch.randn(B, N, 3, H, 64, generator=g)
+    qkv[0, 3900, 1] = qkv[0, 70, 0] * 8.0   # key 3900 aligned with query 70
+    qkv[0, 3, 1] = qkv[0, 2049, 0] * 6.0    # key 3 aligned with query 2049
+    qkv = G.bf16_round(qkv)
+    ref = _attn_ref(qkv, None)
+    _lib.check(_lib.load().f5_tuning_set(b"attn_variant", variant))
+    try:
+        out = G.op_attention(P_BF16, 1, qkv, None)
+    finally:
+        _lib.check(_lib.load().f5_tuning_set(b"attn_variant", 0))
+    assert rel_l2(out, ref) < 6e-3
+
+
 def test_attention_tuned_kernel_spiked_scores():
     """online-softmax rescale path: one key dominates late in the sequence (running max jumps by > 60)."""
     import gpu_helpers as G

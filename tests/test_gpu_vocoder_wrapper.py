@@ -29,7 +29,8 @@ def _vocos(V, **hp):
     return v.cuda()
 
 
-@pytest.mark.parametrize("B,T", [(1, 40), (2, 129), (3, 7)])
+# (2, 683) / (1, 2731): the C5 lengths -- the generated part of a C2 utterance (1024 - 341 frames) and of a C4 one (4096 - 1365)
+@pytest.mark.parametrize("B,T", [(1, 40), (2, 129), (3, 7), (2, 683), (1, 2731)])
 def test_vocos_decode_matches_oracle(B, T):
     V = cpu_ref.random_vocos_weights(seed=3)
     voc = _vocos(V)
@@ -140,3 +141,65 @@ def test_wrapper_end_to_end(tmp_path):
     assert tts.calculate_duration_with_predictor(tok, ln, local_speed=0.5) == tts.ref_audio_len + int(float(torch.exp(logd)) / 0.5)
     with pytest.raises((RuntimeError, ValueError)):  # the reference's reduction leaves [nt] values: .item() refuses more than one token
         tts.calculate_duration_with_predictor(torch.tensor([[5, 6, 7]], device="cuda"), torch.tensor([3], device="cuda"))
+
+
+def test_infer_process_batch_process_and_safetensors_checkpoint(tmp_path):
+    """utils_infer.load_model on a .safetensors EMA checkpoint (reference utils_infer.py:184-226, f5tts_wrapper.py:224-229),
+    infer_process / infer_batch_process (reference utils_infer.py:366-563): chunk bookkeeping, the streaming generator, and the
+    ORIGINAL-rms rule of infer_batch_process (:440-442,491-492), all over the HIP sampler + HIP vocoder."""
+    from safetensors.torch import save_file
+    from eraxvif5tts_amd.infer import audio, utils_infer as U
+    from eraxvif5tts_amd.model import DiT
+    arch = dict(dim=128, depth=2, heads=2, ff_mult=2, text_dim=64, conv_layers=2, pe_attn_head=1, text_mask_padding=False)
+    V = 32
+    W = cpu_ref.random_dit_weights(arch, V, seed=15)
+    hp = dict(dim=64, intermediate_dim=128, num_layers=2)
+    VW = cpu_ref.random_vocos_weights(seed=16, dim=64, inter=128, layers=2)
+    cfg_path, ckpt_pt, vdir, vocab = _write_tiny_assets(str(tmp_path), arch, V, W, hp, VW)
+    ema = {"ema_model.transformer." + k: v.contiguous() for k, v in W.items()}
+    ema.update({"initted": torch.tensor(True), "step": torch.tensor(7)})
+    ckpt_st = os.path.join(str(tmp_path), "model_7.safetensors")
+    save_file(ema, ckpt_st)
+    model = U.load_model(DiT, {**arch, "precision": "fp32"}, ckpt_st, vocab_file=vocab, device="cuda")
+    model_pt = U.load_model(DiT, {**arch, "precision": "fp32"}, ckpt_pt, vocab_file=vocab, device="cuda")
+    sd, sd_pt = model.state_dict(), model_pt.state_dict()
+    assert set(sd) == set(sd_pt)
+    for k in sd:
+        assert torch.equal(sd[k], sd_pt[k]), k
+        if k.startswith("transformer.") and k[len("transformer."):] in W:
+            assert torch.equal(sd[k].cpu(), W[k[len("transformer."):]]), k
+    vocoder = U.load_vocoder(is_local=True, local_path=vdir, device="cuda")
+
+    sr = 24000
+    t = np.arange(int(1.5 * sr)) / sr
+    wav = 0.02 * np.sin(2 * np.pi * 200 * t) * (1 + 0.4 * np.sin(2 * np.pi * 2 * t))  # quieter than target_rms = 0.1
+    ref_wav = os.path.join(str(tmp_path), "ref2.wav")
+    audio.write_wav(ref_wav, wav, sr)
+    ref_file, ref_text = U.preprocess_ref_audio_text(ref_wav, "a quiet tone")
+    assert ref_text == "a quiet tone. "
+    gen_text = "hello there, this is a test. " * 3 + "and one more sentence to force a second chunk, because the budget is small."
+    a, rate = U._load_audio(ref_file)
+    n_chunks = len(U.chunk_text(gen_text, max_chars=int(len(ref_text.encode()) / (a.shape[-1] / rate) * (22 - a.shape[-1] / rate))))
+    assert n_chunks >= 2
+    torch.manual_seed(5)
+    wave, rate_out, spec = U.infer_process(ref_file, ref_text, gen_text, model, vocoder, nfe_step=4, device="cuda")
+    assert rate_out == 24000 and np.isfinite(wave).all() and spec.shape[0] == 100
+    assert len(wave) == (spec.shape[1] - n_chunks) * 256 - (n_chunks - 1) * 3600
+
+    # streaming generator: the chunks of every text batch concatenate to the batch's whole wave (no cross-fade in streaming mode)
+    batches = U.chunk_text(gen_text, max_chars=60)[:2]
+    torch.manual_seed(6)
+    chunks = list(U.infer_batch_process((a, rate), ref_text, batches, model, vocoder, nfe_step=2, device="cuda", streaming=True, chunk_size=1000))
+    assert all(c[1] == 24000 and 0 < len(c[0]) <= 1000 for c in chunks)
+    torch.manual_seed(6)
+    whole, _, _ = next(U.infer_batch_process((a, rate), ref_text, batches, model, vocoder, nfe_step=2, device="cuda", cross_fade_duration=0))
+    assert np.array_equal(np.concatenate([c[0] for c in chunks]), whole)
+
+    # original-rms rule: a prompt quieter than the target is boosted for conditioning and the output scaled back by rms / target
+    rms = float(torch.sqrt(torch.mean(torch.square(a))))
+    assert rms < 0.1
+    torch.manual_seed(7)
+    quiet, _, _ = next(U.infer_batch_process((a, rate), ref_text, batches[:1], model, vocoder, nfe_step=2, device="cuda"))
+    torch.manual_seed(7)
+    loud, _, _ = next(U.infer_batch_process((a * 0.1 / rms, rate), ref_text, batches[:1], model, vocoder, nfe_step=2, device="cuda"))
+    assert np.abs(quiet - loud * (rms / 0.1)).max() <= 2e-3 * np.abs(loud).max() + 1e-6

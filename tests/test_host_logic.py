@@ -68,7 +68,7 @@ def test_c_abi_exports_every_declared_symbol():
     missing = [n for n in declared if not hasattr(lib, n)]
     assert not missing, missing
     assert sorted(_lib.EXPORTS) == declared
-    assert lib.f5_version() == 100
+    assert lib.f5_version() == 200
 
 
 def test_product_path_fails_loudly_without_gpu():
@@ -196,3 +196,14 @@ def test_streaming_wire_format():
     assert parts[0] == h and len(parts) == 3
     assert parts[1] == np.full(3, 8191, np.int16).tobytes() and len(parts[2]) == 2 * len("hello.")
     assert m.ref_text is None and m.ref_audio_processed is None  # state cleared after the request
+
+
+def test_bench_refuses_a_rank_count_that_contradicts_gpus():
+    """bench.py --gpus N: a launcher-provided WORLD_SIZE that differs from N is an error before any GPU work (the flag used to
+    be parsed and ignored, so `--gpus 8` could silently measure one GPU)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "contradicts WORLD_SIZE=4" in r.stderr

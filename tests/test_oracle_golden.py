@@ -104,3 +104,16 @@ def test_duration_predictor_matches_reference_fixture():
     assert rel_l2(cpu_ref.duration_predictor(W, tokens.clamp(min=0), mask, add_one=False), torch.from_numpy(g["out_phoneme"])) < 2e-6
     assert rel_l2(cpu_ref.duration_predictor(W, tokens[2:3, :1], mask[2:3, :1]), torch.from_numpy(g["out_one_token"])) < 2e-6
     assert torch.count_nonzero(torch.from_numpy(g["out"])[mask.unsqueeze(1) == 0]) == 0  # padded tokens carry no duration
+
+
+def test_rope_layout_switch_of_the_oracle():
+    """The half-split rotary form behind cfg["rope_layout"]: permuting the head features (new 2j <- j, new 2j+1 <- j+32) turns it
+    into the adjacent-pair form exactly -- the identity the HIP path uses to serve both layouts with one kernel (csrc/model.hip)."""
+    g = torch.Generator().manual_seed(0)
+    t = torch.randn(2, 3, 11, 64, generator=g)
+    ang = cpu_ref.rope_angles(11)
+    perm = torch.stack([torch.arange(32), torch.arange(32) + 32], dim=1).flatten()  # new feature index -> old feature index
+    a = cpu_ref.apply_rope(t, ang, half_split=True)[..., perm]
+    b = cpu_ref.apply_rope(t[..., perm], ang, half_split=False)
+    assert torch.equal(a, b)
+    assert not torch.allclose(cpu_ref.apply_rope(t, ang, True), cpu_ref.apply_rope(t, ang, False))
