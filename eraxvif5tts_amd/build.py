@@ -22,6 +22,11 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-
          "-Wno-unused-but-set-variable", "-ffp-contract=off"]
 
 
+# per-file extra flags: the hand-laid vector stream of the attention kernel must not be re-packed into v_pk_*_f32 by the SLP vectorizer
+# (packed fp32 VALU is slower beside MFMAs: /opt/skills/guides/MI355X_MICROARCH.md, cycle constants)
+EXTRA_FLAGS = {"attention_pipe.hip": ["-fno-slp-vectorize"]}
+
+
 def _hipcc():
     for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -40,6 +45,7 @@ def _digest():
             h.update(f.encode())
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -54,7 +60,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(src):
         obj = os.path.join(BUILD, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")

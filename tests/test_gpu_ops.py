@@ -83,9 +83,9 @@ def _fused_ref(epi, A, W, b, act, gate, rowmask, rope, rope_heads, seq):
     return v.float()
 
 
-# whole-tile shapes (lean epilogue), ragged rows / narrow tiles (generic epilogue), >= 160 tiles (where the 4-wave kernel applies)
-@pytest.mark.parametrize("knobs", [{}, {"gemm_persist": 0}, {"gemm_persist": 0, "gemm_lean": 0}, {"gemm_big": 1}],
-                         ids=["default_persistent_grid", "one_tile_per_workgroup", "generic_epilogue", "four_wave_kernel"])
+# whole-tile shapes (lean epilogue), ragged rows / narrow tiles (generic epilogue), every schedule the launcher can pick
+@pytest.mark.parametrize("knobs", [{}, {"gemm_persist": 0}, {"gemm_persist": 0, "gemm_lean": 0}, {"gemm_variant": 0}],
+                         ids=["default_persistent_grid", "one_tile_per_workgroup", "generic_epilogue", "plain_ring"])
 @pytest.mark.parametrize("epi_name,shape,seq", [("store", (512, 1024, 256), 0), ("store", (10240, 1024, 128), 0), ("store", (10300, 2048, 192), 0),
                                                 ("gate", (768, 512, 128), 0), ("gate", (10240, 1024, 256), 0), ("gate", (10301, 1024, 128), 0),
                                                 ("rope", (1024, 768, 128), 256), ("rope", (4096, 3072, 128), 1024), ("rope", (4120, 3072, 128), 1030)])
@@ -111,7 +111,7 @@ def test_linear_fused_epilogues(knobs, epi_name, shape, seq):
         out = G.op_linear_fused(1, epi, A, W, b, act, gate, rowmask, rope, heads, seq)
     finally:
         for k in knobs:
-            _lib.check(lib.f5_tuning_set(k.encode(), {"gemm_lean": 1, "gemm_big": 0, "gemm_persist": 1}[k]))
+            _lib.check(lib.f5_tuning_set(k.encode(), {"gemm_lean": 1, "gemm_variant": 1, "gemm_persist": 1}[k]))
     base = G.op_linear_fused(0, epi, A, W, b, act, gate, rowmask, rope, heads, seq)
     assert rel_l2(base, ref) < 3e-3   # bf16 output rounding: 2^-9 relative per element
     assert rel_l2(out, ref) < 3e-3
@@ -205,7 +205,7 @@ def test_linear_tuned_kernel(shape, act):
 
 @pytest.mark.parametrize("B,N,H,masked", [(2, 56, 2, True), (1, 41, 2, False), (2, 200, 3, True), (1, 128, 16, False), (2, 1024, 4, True),
                                           (1, 1024, 2, False), (3, 333, 1, True)])
-@pytest.mark.parametrize("variant", [0, 3], ids=["register_staged", "lds_dma_staged"])
+@pytest.mark.parametrize("variant", [0, 2, 5], ids=["by_grid_size", "64_queries_per_wave", "pipelined_32_queries_per_wave"])
 def test_attention_tuned_kernel(B, N, H, masked, variant):
     import gpu_helpers as G
     from eraxvif5tts_amd import _lib
@@ -228,7 +228,7 @@ def test_attention_tuned_kernel(B, N, H, masked, variant):
     assert (out[valid] - ref[valid]).abs().max() < 0.05
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2], ids=["default_by_length", "32_queries_per_wave", "64_queries_per_wave"])
+@pytest.mark.parametrize("variant", [0, 2, 5], ids=["by_grid_size", "64_queries_per_wave", "pipelined_32_queries_per_wave"])
 @pytest.mark.parametrize("N", [2048, 2050, 4000, 4096])
 @pytest.mark.parametrize("masked", [False, True], ids=["unmasked", "ragged_lens"])
 def test_attention_tuned_kernel_long_sequences(variant, N, masked):
@@ -256,7 +256,7 @@ def test_attention_tuned_kernel_long_sequences(variant, N, masked):
     assert (out[valid] - ref[valid]).abs().max() < 0.05
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 2, 5])
 def test_attention_long_sequence_spiked_scores(variant):
     """online-softmax rescale path of every schedule at N = 4096: the running max jumps late (key 3900) and in the first tile."""
     import gpu_helpers as G
@@ -274,6 +274,35 @@ def test_attention_long_sequence_spiked_scores(variant):
     finally:
         _lib.check(_lib.load().f5_tuning_set(b"attn_variant", 0))
     assert rel_l2(out, ref) < 6e-3
+
+
+@pytest.mark.parametrize("variant", [2, 5])
+def test_attention_deferred_rescale_thresholds(variant):
+    """The deferred rescale (a row's exponent reference moves only when its maximum outgrew it by more than 2^16): score jumps just below
+    and far above the threshold, early and late, and a row whose maximum keeps creeping up tile by tile -- against the fp64 softmax."""
+    import gpu_helpers as G
+    from eraxvif5tts_amd import _lib
+    g = torch.Generator().manual_seed(9)
+    B, N, H = 1, 1024, 2
+    qkv = torch.randn(B, N, 3, H, 64, generator=g) * 0.5
+    qn = qkv[0, :, 0] / qkv[0, :, 0].norm(dim=-1, keepdim=True)      # unit queries
+    for q, (key, nat) in {5: (700, 10.0), 37: (130, 12.5), 90: (1000, 40.0), 200: (3, 60.0)}.items():
+        qkv[0, q, 0] = qn[q] * 8.0                                   # |q| = 8: q.k / 8 = |k| cos
+        qkv[0, key, 1] = qn[q] * nat                                 # score of (q, key) = nat nats (16 log2 units = 11.1 nats)
+    qkv[0, 300, 0] = qn[300] * 8.0
+    for i, key in enumerate(range(10, 1024, 64)):                    # one key per tile, each 1.5 nats above the previous
+        qkv[0, key, 1] = qn[300] * (1.5 * (i + 1))
+    qkv = G.bf16_round(qkv)
+    ref = _attn_ref(qkv, None)
+    _lib.check(_lib.load().f5_tuning_set(b"attn_variant", variant))
+    try:
+        out = G.op_attention(P_BF16, 1, qkv, None)
+    finally:
+        _lib.check(_lib.load().f5_tuning_set(b"attn_variant", 0))
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) < 6e-3
+    for q in (5, 37, 90, 200, 300):
+        assert (out[0, q] - ref[0, q]).abs().max() < 0.03 * max(1.0, float(ref[0, q].abs().max())), q
 
 
 def test_attention_tuned_kernel_spiked_scores():
