@@ -177,7 +177,7 @@ def test_infer_process_batch_process_and_safetensors_checkpoint(tmp_path):
     audio.write_wav(ref_wav, wav, sr)
     ref_file, ref_text = U.preprocess_ref_audio_text(ref_wav, "a quiet tone")
     assert ref_text == "a quiet tone. "
-    gen_text = "hello there, this is a test. " * 3 + "and one more sentence to force a second chunk, because the budget is small."
+    gen_text = "hello there, this is a test. " * 6 + "and one more sentence to force a second chunk, because the budget is small."
     a, rate = U._load_audio(ref_file)
     n_chunks = len(U.chunk_text(gen_text, max_chars=int(len(ref_text.encode()) / (a.shape[-1] / rate) * (22 - a.shape[-1] / rate))))
     assert n_chunks >= 2
