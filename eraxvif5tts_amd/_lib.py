@@ -29,6 +29,10 @@ class VocosConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_mels", "dim", "inter_dim", "layers", "n_fft", "hop")]
 
 
+class MelConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_fft", "hop", "win", "n_mels", "sample_rate")]
+
+
 class DurationWeights(C.Structure):  # struct f5_duration_weights
     _fields_ = [(n, C.c_void_p) for n in ("text_embed", "conv1_w", "conv1_b", "norm1_w", "norm1_b", "conv2_w", "conv2_b", "norm2_w", "norm2_b",
                                           "proj_w", "proj_b")] + [(n, C.c_int32) for n in ("vocab_rows", "in_channels", "filter_channels", "kernel_size")]
@@ -72,6 +76,10 @@ _PROTOS = {
     "f5_vocoder_destroy": (_I, [_P]),
     "f5_vocoder_decode": (_I, [_P, _I, _I, _P, _P, _P]),
     "f5_vocoder_istft_head": (_I, [_P, _I, _I, _P, _P, _P]),
+    "f5_frontend_create": (_I, [C.POINTER(MelConfig), C.POINTER(_P)]),
+    "f5_frontend_destroy": (_I, [_P]),
+    "f5_frontend_mel": (_I, [_P, _I, _I, _P, _P, _P]),
+    "f5_frontend_resample": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
 }
 EXPORTS = tuple(_PROTOS)
 

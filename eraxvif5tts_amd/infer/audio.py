@@ -225,6 +225,9 @@ def segment_to_float(seg):
 def resample(waveform, orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99):
     if orig_freq == new_freq:
         return waveform
+    if waveform.is_cuda and lowpass_filter_width == 6 and rolloff == 0.99:  # device path: csrc/frontend.hip (same kernel table, fp32 FIR)
+        from ..frontend import resample as _hip_resample
+        return _hip_resample(waveform, orig_freq, new_freq)
     g = math.gcd(int(orig_freq), int(new_freq))
     orig, new = int(orig_freq) // g, int(new_freq) // g
     base_freq = min(orig, new) * rolloff

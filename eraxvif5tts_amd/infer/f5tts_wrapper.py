@@ -126,9 +126,9 @@ class F5TTSWrapper:
         rms = torch.sqrt(torch.mean(torch.square(audio)))
         if rms < self.target_rms:  # boosted only when quieter than the target (reference :334-336)
             audio = audio * self.target_rms / rms
-        if sr != self.target_sample_rate:
-            audio = _audio.resample(audio, sr, self.target_sample_rate)
         audio = audio.to(self.device)
+        if sr != self.target_sample_rate:
+            audio = _audio.resample(audio, sr, self.target_sample_rate)  # on the device (f5_frontend_resample)
         self.ref_audio_processed = audio
         self.ref_text = ref_text
         self.ref_audio_len = audio.shape[-1] // self.hop_length

@@ -195,9 +195,9 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
     rms = torch.sqrt(torch.mean(torch.square(audio)))  # the ORIGINAL (pre-boost) rms scales the output back (reference :440-442,491-492)
     if rms < target_rms:
         audio = audio * target_rms / rms
-    if sr != target_sample_rate:
-        audio = _audio.resample(audio, sr, target_sample_rate)
     audio = audio.to(device)
+    if sr != target_sample_rate:
+        audio = _audio.resample(audio, sr, target_sample_rate)  # on the device (f5_frontend_resample)
     if len(ref_text[-1].encode("utf-8")) == 1:
         ref_text = ref_text + " "
 

@@ -3,7 +3,8 @@
 Only the ``vocos`` mel type of the hot path is provided (the bigvgan variant belongs to another vocoder, out of scope).
 torchaudio is not a dependency: ``MelSpectrogram(sr 24000, n_fft 1024, win 1024, hop 256, n_mels 100, power=1, center=True,
 norm=None, mel_scale='htk')`` is written out with ``torch.stft`` (periodic Hann, reflect padding) and the HTK triangular
-filterbank, then ``clamp(min=1e-5).log()``.  It runs on whatever device the waveform lives on, once per ``sample()``.
+filterbank, then ``clamp(min=1e-5).log()``.  A waveform on the GPU -- the inference path: the wrapper keeps the prompt on the device --
+goes through libf5hip (``f5_frontend_mel``); the ``torch.stft`` form below only serves host-resident tensors.
 """
 from __future__ import annotations
 
@@ -31,6 +32,11 @@ def get_vocos_mel_spectrogram(waveform, n_fft=1024, n_mel_channels=100, target_s
     if waveform.ndim == 3:
         waveform = waveform.squeeze(1)
     assert waveform.ndim == 2
+    if waveform.is_cuda:  # the hot path: HIP kernels (frames -> DFT on the fp32-input MFMA -> magnitude -> HTK filterbank -> log), csrc/frontend.hip
+        from ..frontend import mel_spectrogram
+        return mel_spectrogram(waveform, n_fft=n_fft, hop_length=hop_length, win_length=win_length, n_mel_channels=n_mel_channels,
+                               target_sample_rate=target_sample_rate).to(waveform.dtype)
+    # host-resident waveforms (the reference is CPU-runnable too; only the CPU tests come here)
     wav = waveform.float()
     window = torch.hann_window(win_length, periodic=True, device=wav.device)
     spec = torch.stft(wav, n_fft, hop_length=hop_length, win_length=win_length, window=window, center=True, pad_mode="reflect",

@@ -224,6 +224,25 @@ int f5_vocoder_decode(f5_vocoder_t v, int B, int T, const float* mel, float* wav
  * log-magnitude | phase) -> wave dev f32 [B, (T-1)*hop] */
 int f5_vocoder_istft_head(f5_vocoder_t v, int B, int T, const float* head_out, float* wave, f5_stream_t stream);
 
+/* ------------------------------------------------------------------ reference-audio front-end on the device
+ * Replaces the two torchaudio transforms of the path:
+ *   f5_frontend_mel       MelSpec / get_vocos_mel_spectrogram, reference model/modules.py:75-143 (as called from cfm.py:103-105):
+ *                         wave dev f32 [B, nw] -> log-mel dev f32 [B, n_mels, nw / hop + 1]
+ *   f5_frontend_resample  torchaudio.transforms.Resample(sr, target) of F5TTSWrapper.preprocess_reference (infer/f5tts_wrapper.py:338-341) and
+ *                         infer_batch_process (infer/utils_infer.py:443-445): wave dev f32 [B, n] -> dev f32 [B, ceil(new * n / orig)] */
+typedef struct f5_frontend_s* f5_frontend_t;
+typedef struct f5_mel_config {
+    int32_t n_fft;       /* 1024 */
+    int32_t hop;         /* 256 */
+    int32_t win;         /* 1024 (<= n_fft; centred) */
+    int32_t n_mels;      /* 100 */
+    int32_t sample_rate; /* 24000: the filterbank spans 0 .. sample_rate / 2 */
+} f5_mel_config;
+int f5_frontend_create(const f5_mel_config* cfg, f5_frontend_t* out);
+int f5_frontend_destroy(f5_frontend_t h);
+int f5_frontend_mel(f5_frontend_t h, int B, int nw, const float* wave, float* mel, f5_stream_t stream);
+int f5_frontend_resample(f5_frontend_t h, int B, int n, int orig_freq, int new_freq, const float* wave, float* out, f5_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

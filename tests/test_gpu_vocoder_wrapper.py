@@ -203,3 +203,42 @@ def test_infer_process_batch_process_and_safetensors_checkpoint(tmp_path):
     torch.manual_seed(7)
     loud, _, _ = next(U.infer_batch_process((a * 0.1 / rms, rate), ref_text, batches[:1], model, vocoder, nfe_step=2, device="cuda"))
     assert np.abs(quiet - loud * (rms / 0.1)).max() <= 2e-3 * np.abs(loud).max() + 1e-6
+
+
+def test_streaming_wire_over_the_hip_wrapper(tmp_path):
+    """SURVEY 8(f).1 on the real path: streaming.wire.stream_audio over the HIP F5TTSWrapper (HIP sampler + HIP vocoder) emits the 44-byte
+    unknown-size WAV header and then, per text chunk, exactly the int16 PCM of generate()'s output for that chunk (reference
+    src/streaming/f5tts-fastapi-server.py:173-204,246-250,270-421); the reference cache installs / clears the wrapper's state."""
+    from eraxvif5tts_amd.infer import audio
+    from eraxvif5tts_amd.infer.f5tts_wrapper import F5TTSWrapper
+    from eraxvif5tts_amd.streaming.wire import ReferenceCache, create_wave_header, pcm16_bytes, stream_audio
+    arch = dict(dim=128, depth=2, heads=2, ff_mult=2, text_dim=64, conv_layers=2, pe_attn_head=1, text_mask_padding=False)
+    V = 32
+    W = cpu_ref.random_dit_weights(arch, V, seed=25)
+    hp = dict(dim=64, intermediate_dim=128, num_layers=2)
+    VW = cpu_ref.random_vocos_weights(seed=26, dim=64, inter=128, layers=2)
+    cfg_path, ckpt, vdir, vocab = _write_tiny_assets(str(tmp_path), arch, V, W, hp, VW)
+    sr = 24000
+    t = np.arange(int(1.6 * sr)) / sr
+    ref_wav = os.path.join(str(tmp_path), "spk.wav")
+    audio.write_wav(ref_wav, 0.05 * np.sin(2 * np.pi * 220 * t), sr)
+    tts = F5TTSWrapper(model_name=cfg_path, ckpt_path=ckpt, vocab_file=vocab, use_local_vocoder=True, vocoder_path=vdir)
+    cache = ReferenceCache()
+    entry = cache.add(tts, "spk", ref_wav, text="a steady tone")
+    assert entry["loaded"] is True and entry["processed_text"] == "a steady tone. " and tts.ref_audio_processed is None
+    bad = cache.add(tts, "broken", os.path.join(str(tmp_path), "missing.wav"), text="x")
+    assert bad["loaded"] is False and bad["error"]
+    with pytest.raises(LookupError, match="not ready"):
+        next(stream_audio(tts, cache, "broken", ["x"]))
+    chunks = ["hello there.", "   ", "this is the second chunk..", "and a third one, a little longer than the others."]
+    torch.manual_seed(11)
+    parts = list(stream_audio(tts, cache, "spk", chunks, nfe_step=4))
+    assert tts.ref_audio_processed is None and tts.ref_text is None  # cleared after the request (:419-421)
+    assert parts[0] == create_wave_header(24000) and len(parts[0]) == 44 and len(parts) == 4  # the blank chunk yields nothing
+    # the same requests one by one through generate(), same noise stream
+    cache.install(tts, "spk")
+    torch.manual_seed(11)
+    for text, got in zip(("hello there.", "this is the second chunk.", "and a third one, a little longer than the others."), parts[1:]):
+        wave, rate = tts.generate(text=text, return_numpy=True, nfe_step=4)
+        assert rate == 24000 and got == pcm16_bytes(wave) and len(got) == 2 * len(wave) and np.isfinite(wave).all()
+    cache.clear(tts)
