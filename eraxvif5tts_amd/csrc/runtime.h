@@ -22,6 +22,7 @@ struct DevArena {
 };
 
 int f5_check_device();                       // F5_ENODEVICE unless a gfx950 device is current
+int f5_cu_count();                           // compute units of the current device (cached; 256 on MI355X)
 uint16_t f5_f32_to_bf16_bits(float f);       // round-to-nearest-even, NaN preserved
 size_t f5_elem_size(int precision);          // 2 (bf16) / 4 (fp32)
 // upload host fp32 -> device in the activation dtype of `precision` (bf16 RNE on the host) / as fp32

@@ -59,6 +59,16 @@ int f5_check_device() {
     return 0;
 }
 
+int f5_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n;
+    }
+    return cus;
+}
+
 int DevArena::alloc(void** out, size_t bytes, bool zero) {
     *out = nullptr;
     if (bytes == 0) bytes = 16;

@@ -240,3 +240,29 @@ def test_c4_long_form_sampler_bf16_vs_fp32_mode():
     err = rel_l2(gen(outs["bf16"]), gen(outs["fp32"]))
     print(f"C4 bf16 vs fp32 mode, 22 blocks x 2 steps, N = 4096: rel-L2 {err:.3e}")
     assert err < 2e-2
+
+
+def test_c3_shard_shape_matches_other_batch_sizes():
+    """C3's per-GPU shape at 8 GPUs (4 utterances x 1024 frames, CFG doubling -> 8192 token rows): at this size the fused QKV projection is
+    issued as a q|k launch plus a v launch (tile quantisation, csrc/model.hip).  Every utterance of the 4-batch must equal the same
+    utterance sampled in a batch of two (which takes the single-launch path): the shard a rank computes does not depend on how the
+    32 utterances were split (eval_infer_batch.py:163)."""
+    import bench
+    from eraxvif5tts_amd.model import CFM, DiT
+    model = bench.synth_weights(DiT(**bench.BASE_ARCH, text_num_embeds=bench.VOCAB, mel_dim=100, precision="bf16"))
+    cfm = CFM(transformer=model, mel_spec_kwargs={"mel_spec_type": "vocos"}).cuda()
+    B, N = 4, 1024
+    cond, text, lens, dur = bench.synth_batch(B, N, "cuda", seed=13)
+    g = torch.Generator().manual_seed(14)
+    dur = dur - torch.tensor([0, 37, 150, 3], device="cuda")
+    y0 = torch.randn(B, N, 100, generator=g)
+    y0 = y0 * (torch.arange(N)[None, :, None] < dur.cpu()[:, None, None])
+    kw = dict(steps=2, cfg_strength=2.0, sway_sampling_coef=-1.0, return_trajectory=False)
+    full, _ = cfm.sample(cond=cond, text=text, duration=dur, lens=lens, y0=y0, **kw)
+    assert torch.isfinite(full).all()
+    for i in (1, 2, 3):
+        idx = torch.tensor([0, i], device="cuda")
+        sub, _ = cfm.sample(cond=cond[idx], text=text[idx], duration=dur[idx], lens=lens[idx], y0=y0[idx.cpu()], **kw)
+        for j, src in enumerate((0, i)):
+            d = int(dur[src])
+            assert rel_l2(sub[j, :d].cpu(), full[src, :d].cpu()) < 1e-6, (i, j)

@@ -242,3 +242,47 @@ def test_streaming_wire_over_the_hip_wrapper(tmp_path):
         wave, rate = tts.generate(text=text, return_numpy=True, nfe_step=4)
         assert rate == 24000 and got == pcm16_bytes(wave) and len(got) == 2 * len(wave) and np.isfinite(wave).all()
     cache.clear(tts)
+
+
+def test_generate_long_form_chunks_and_cross_fade(tmp_path):
+    """C4's chunk-and-cross-fade variant through generate() (reference infer/f5tts_wrapper.py:459-461,541-575): an 8 s prompt and a text long
+    enough for several chunks of <= 22 s each, i.e. sequences of ~2000 frames per sample() call; the chunks are synthesised one by one
+    and joined with 0.15 s (3600-sample) linear cross-fades.  Checked: chunk count = chunk_text's, every chunk's frame budget follows
+    the byte-ratio duration rule, total length = sum of chunks - overlaps, the fade region is the linear blend of the two neighbours."""
+    from eraxvif5tts_amd.infer import audio
+    from eraxvif5tts_amd.infer.f5tts_wrapper import F5TTSWrapper
+    from eraxvif5tts_amd.infer.utils_infer import chunk_text
+    arch = dict(dim=128, depth=2, heads=2, ff_mult=2, text_dim=64, conv_layers=2, pe_attn_head=1, text_mask_padding=False)
+    V = 32
+    W = cpu_ref.random_dit_weights(arch, V, seed=35)
+    hp = dict(dim=64, intermediate_dim=128, num_layers=2)
+    VW = cpu_ref.random_vocos_weights(seed=36, dim=64, inter=128, layers=2)
+    cfg_path, ckpt, vdir, vocab = _write_tiny_assets(str(tmp_path), arch, V, W, hp, VW)
+    sr = 24000
+    t = np.arange(8 * sr) / sr
+    ref_wav = os.path.join(str(tmp_path), "long_ref.wav")
+    audio.write_wav(ref_wav, 0.2 * np.sin(2 * np.pi * 150 * t) * (1 + 0.3 * np.sin(2 * np.pi * 2 * t)), sr)
+    tts = F5TTSWrapper(model_name=cfg_path, ckpt_path=ckpt, vocab_file=vocab, use_local_vocoder=True, vocoder_path=vdir)
+    ref_text = "this is the reference sentence that goes with the eight second prompt, spoken at an even pace."
+    tts.preprocess_reference(ref_wav, ref_text, clip_short=False)
+    sentence = "the quick brown fox jumps over the lazy dog, and then it does so once more. "
+    text = sentence * 6
+    secs = tts.get_current_audio_length()
+    max_chars = int(len(tts.ref_text.encode()) / secs * (22 - secs))
+    chunks = chunk_text(text, max_chars=max_chars)
+    assert len(chunks) >= 3
+    # per-chunk waves with cross-fade off, then the joined wave with the default 0.15 s fade (same noise: same seeds per call)
+    torch.manual_seed(21)
+    plain, rate, spec = tts.generate(text, nfe_step=2, cross_fade_duration=0.0, return_numpy=True, return_spectrogram=True)
+    torch.manual_seed(21)
+    faded, _ = tts.generate(text, nfe_step=2, return_numpy=True)
+    frames = [tts.ref_audio_len + int(tts.ref_audio_len / len(tts.ref_text.encode()) * len(c.encode()) / 1.0) for c in chunks]
+    assert max(frames) > 1500 and max(frames) <= 2100  # <= 22 s per sample() call
+    lens = [(f - tts.ref_audio_len - 1) * 256 for f in frames]  # generated frames minus the overlap frame, vocoded
+    assert rate == 24000 and len(plain) == sum(lens) and spec.shape[1] == sum(f - tts.ref_audio_len for f in frames)
+    n = 3600
+    assert len(faded) == sum(lens) - n * (len(chunks) - 1)
+    first, second = plain[: lens[0]], plain[lens[0]: lens[0] + lens[1]]
+    blend = first[-n:] * np.linspace(1, 0, n) + second[:n] * np.linspace(0, 1, n)
+    assert np.allclose(faded[lens[0] - n: lens[0]], blend, atol=1e-6) and np.array_equal(faded[: lens[0] - n], first[:-n])
+    assert np.isfinite(faded).all()
