@@ -20,6 +20,7 @@
 #include "kernels.h"
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
 __device__ __forceinline__ float max3_asm(float a, float b, float c) {
     float d;
@@ -222,22 +223,34 @@ __global__ __launch_bounds__(256, 2) void attn_fast2_kernel(const bf16_t* __rest
         if (t + 2 < nt) load_tile((t + 2) * KT);
     }
 
+    // ---- normalise; stage the wave's 64 x 64 output block through LDS (the K/V buffers are free: the loop ended on a barrier) and store
+    //      whole 128-byte rows: a wave-instruction then writes 8 full lines instead of 8-byte pieces of 32 different rows (the per-lane
+    //      form is store-ISSUE bound: 16 dwordx2 per lane; C2 spends ~15 % of a workgroup's life in that tail, C4 a quarter of that)
+    char* stage = smem + wave * (64 * 128);
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
         const float l_tot = l_run[j] + __shfl_xor(l_run[j], 32, 64);
         const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-        const int qrow = q0 + 32 * j + r;
-        if (qrow < N) {
-            bf16_t* op = out + ((size_t)b * N + qrow) * ldo + head * 64 + 4 * h;
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    bf16x4 v4;
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 v4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)(o_acc[j][mb][4 * g + e] * inv);
-                    *reinterpret_cast<bf16x4*>(op + 32 * mb + 8 * g) = v4;
-                }
+                for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)(o_acc[j][mb][4 * g + e] * inv);
+                // row 32*j + r, dims 32*mb + 8*g + 4*h .. +3; 16-byte chunk index XORed with the row so that the 32 rows of a
+                // half-wave spread over the banks
+                const int row = 32 * j + r, chunk = (4 * mb + g) ^ (row & 7);
+                *reinterpret_cast<bf16x4*>(stage + row * 128 + chunk * 16 + 8 * h) = v4;
+            }
+    }
+    {
+        bf16_t* obase = out + ((size_t)b * N + q0) * ldo + head * 64;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int row = 8 * k + (lane >> 3), chunk = lane & 7;
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(stage + row * 128 + ((chunk ^ (row & 7)) * 16));
+            if (q0 + row < N) *reinterpret_cast<u32x4_t*>(obase + (size_t)row * ldo + chunk * 8) = v;
         }
     }
 }
@@ -249,7 +262,7 @@ bool attention_fast_supported(int precision, int N, int H) { return precision ==
 int launch_attention_pipe(int waves, int B, int N, int H, const void* qkv, int ldq, const uint8_t* mask, void* out, int ldo, hipStream_t stream);  // attention_pipe.hip
 
 int launch_attention_fast(int B, int N, int H, const void* qkv, int ldq, const uint8_t* mask, void* out, int ldo, hipStream_t stream) {
-    if ((ldq & 7) || (ldo & 3)) return f5_fail(F5_EINVAL, "attention_fast: ldq must be a multiple of 8 and ldo of 4");
+    if ((ldq & 7) || (ldo & 7)) return f5_fail(F5_EINVAL, "attention_fast: ldq and ldo must be multiples of 8");
     // 256 queries per workgroup need at least one workgroup per CU to pay (C2: 753 vs 705 TFLOP/s, C4: 923 vs 867); below that
     // (single-utterance serving) the 128-query workgroups of the pipelined kernel fill the chip better (B = 1: 17 vs 25 us)
     static int cus = 0;
