@@ -192,7 +192,7 @@ def bench_vocos(args, dev):
         "config": {"workload": f"C5 Vocos.decode (vocos-mel-24khz shape, random init): mel [B={B}, 100, T={T}] -> wave [B, {(T - 1) * 256}]",
                    "global_batch": B, "frames": T},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": None, "kernel": "ISTFT head (spectrum -> inverse real DFT -> window -> overlap-add)",
+                     "traffic": None, "kernel": "ISTFT head (exp/clip/cos/sin -> 1024-point inverse FFT in LDS -> window; overlap-add)",
                      "launch": f"{head_bytes / 1e6:.1f} MB algorithmic (5.1 KB per frame) in {head_ms:.4f} ms, mean of {iters} calls (HIP events)",
                      "backbone_tflops_f32": round(flops * args.steps / elapsed / 1e12, 2), "backbone_peak_f32": MFMA_F32_PEAK_TFLOPS},
     }

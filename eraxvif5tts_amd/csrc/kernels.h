@@ -59,5 +59,8 @@ int launch_set_floats(float* dst, const float* host_vals, int n, hipStream_t str
 int launch_vocos_im2col(int precision_out, const float* mel, int B, int C, int T, void* dst, int Kp, hipStream_t stream);
 // head.out activations [B*T, ld] (log-mag | phase) -> spectrum rows [B*T, Kp]: (re_0..re_{F-1}, im_0..im_{F-1}), F = n_fft/2+1
 int launch_vocos_spectrum(int precision_out, const float* head, int ldh, int rows, int F, void* dst, int Kp, hipStream_t stream);
+// ISTFT head for n_fft = 1024 as an FFT: head [rows, ldh] (log-mag | phase) -> windowed frames [rows, 1024]; wscaled = window / n_fft,
+// twiddle = (cos, sin)(2 pi j / 1024)
+int launch_vocos_ifft1024(const float* head, int ldh, int rows, const float* wscaled, const float* twiddle, float* frames, hipStream_t stream);
 // overlap-add of windowed frames [B*T, n_fft] (hop), divide by the window-square envelope, trim n_fft/2 each side
 int launch_vocos_ola(const float* frames, int B, int T, int n_fft, int hop, const float* wsq /*[n_fft]*/, float* wave, hipStream_t stream);

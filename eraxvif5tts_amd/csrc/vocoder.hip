@@ -24,7 +24,7 @@ struct f5_vocoder_s {
     std::vector<float> window;  // head.istft.window (periodic Hann by default)
     std::vector<VocosBlockW> blocks;
     float *w_embed = nullptr, *b_embed = nullptr, *norm_w = nullptr, *norm_b = nullptr, *fnorm_w = nullptr, *fnorm_b = nullptr;
-    float *w_head = nullptr, *b_head = nullptr, *w_dft = nullptr, *wsq = nullptr;
+    float *w_head = nullptr, *b_head = nullptr, *w_dft = nullptr, *wsq = nullptr, *wscaled = nullptr, *twiddle = nullptr;
     int k_embed = 0, ld_head = 0, k_spec = 0, F = 0;
     // workspace
     float *x0 = nullptr, *xres = nullptr, *hT = nullptr, *h2 = nullptr, *head = nullptr, *spec = nullptr, *frames = nullptr;
@@ -154,6 +154,16 @@ extern "C" int f5_vocoder_finalize(f5_vocoder_t v) {
         }
         F5_TRY(f5_upload_f32(A, w.data(), w.size(), &v->w_dft));
         F5_TRY(f5_upload_f32(A, wsq.data(), wsq.size(), &v->wsq));
+        if (NF == 1024) {  // the FFT form of the head (vocos.hip): window / n_fft and the twiddle table
+            std::vector<float> ws(NF), tw(2 * NF);
+            for (size_t n = 0; n < NF; ++n) {
+                ws[n] = (float)(v->window[n] / (double)NF);
+                tw[2 * n] = (float)cos(2.0 * M_PI * (double)n / (double)NF);
+                tw[2 * n + 1] = (float)sin(2.0 * M_PI * (double)n / (double)NF);
+            }
+            F5_TRY(f5_upload_f32(A, ws.data(), ws.size(), &v->wscaled));
+            F5_TRY(f5_upload_f32(A, tw.data(), tw.size(), &v->twiddle));
+        }
     }
     for (auto& kv : v->slots) {
         kv.second.host.clear();
@@ -168,6 +178,8 @@ extern "C" int f5_vocoder_destroy(f5_vocoder_t v) {
     delete v;
     return 0;
 }
+
+int g_vocos_fft = 1;  // tuning knob ("vocos_fft"): ISTFT head by FFT (1) or by the dense inverse-DFT GEMM (0: the parity cross-check)
 
 static int ensure_work(f5_vocoder_s* v, size_t rows) {
     if (rows <= v->work_rows) return 0;
@@ -196,6 +208,10 @@ static GemmParams vg() {
 static int istft_from_head(f5_vocoder_s* v, int B, int T, const float* head, int ldh, float* wave, hipStream_t st) {
     const f5_vocos_config& c = v->cfg;
     const int rows = B * T;
+    if (v->twiddle && g_vocos_fft) {  // n_fft = 1024: inverse FFT in LDS, one workgroup per frame (HBM-bound)
+        F5_TRY(launch_vocos_ifft1024(head, ldh, rows, v->wscaled, v->twiddle, v->frames, st));
+        return launch_vocos_ola(v->frames, B, T, c.n_fft, c.hop, v->wsq, wave, st);
+    }
     F5_TRY(launch_vocos_spectrum(F5_PREC_FP32, head, ldh, rows, v->F, v->spec, v->k_spec, st));
     GemmParams g = vg();
     g.A = v->spec; g.lda = v->k_spec; g.W = v->w_dft; g.ldw = v->k_spec; g.M = rows; g.N = c.n_fft; g.K = v->k_spec;

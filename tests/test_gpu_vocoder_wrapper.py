@@ -64,6 +64,25 @@ def test_istft_head_matches_torch_istft_and_round_trips():
     assert y.shape == x.shape and (y - x).abs().max() < 2e-4
 
 
+def test_istft_head_fft_equals_dense_dft():
+    """The two forms of the ISTFT head in the library: the LDS FFT (production, n_fft = 1024) against the dense inverse-DFT GEMM it replaced
+    (kept behind the `vocos_fft` knob as the cross-check), on random head activations including clipped magnitudes (exp > 1e2)."""
+    from eraxvif5tts_amd import _lib
+    V = cpu_ref.random_vocos_weights(seed=8)
+    voc = _vocos(V)
+    g = torch.Generator().manual_seed(3)
+    B, T = 3, 57
+    head = torch.cat([torch.randn(B, T, 513, generator=g) * 2.0 + 1.0, torch.randn(B, T, 513, generator=g) * 3.0], dim=-1)
+    head[0, 5, :40] = 7.0  # exp(7) > 100: the clip is live
+    fft = voc.istft_head(head.cuda()).cpu()
+    _lib.check(_lib.load().f5_tuning_set(b"vocos_fft", 0))
+    try:
+        dft = voc.istft_head(head.cuda()).cpu()
+    finally:
+        _lib.check(_lib.load().f5_tuning_set(b"vocos_fft", 1))
+    assert torch.isfinite(fft).all() and rel_l2(fft, dft) < 2e-6
+
+
 def _write_tiny_assets(tmp, arch, V, W, vocos_hp, VW):
     cfg = {"model": {"name": "tiny_custom", "backbone": "DiT", "arch": arch,
                      "mel_spec": {"target_sample_rate": 24000, "n_mel_channels": 100, "hop_length": 256, "win_length": 1024, "n_fft": 1024,
