@@ -24,7 +24,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-
 
 # per-file extra flags: the hand-laid vector stream of the attention kernel must not be re-packed into v_pk_*_f32 by the SLP vectorizer
 # (packed fp32 VALU is slower beside MFMAs: /opt/skills/guides/MI355X_MICROARCH.md, cycle constants)
-EXTRA_FLAGS = {"attention_pipe.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"attention_pipe.hip": ["-fno-slp-vectorize"], "attention_fast.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():

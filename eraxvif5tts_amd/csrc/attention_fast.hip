@@ -4,19 +4,16 @@
 //
 // Structure (see /opt/skills/guides/cdna_hip_programming.md, Appendix B "Fused attention prefill"):
 //   * one workgroup = 4 wavefronts = 256 queries of one (batch, head); each wave owns TWO 32-query blocks, so every K fragment,
-//     V^T fragment, K/V tile refresh and barrier is amortised over 64 queries.  What the measurements of round 2 say decides
-//     (profiles/r2_attention_*.txt): on one SIMD the matrix pipe and the vector ALU mostly serialise, and the LDS -> VGPR fragment
-//     traffic is not hidden by either, so halving the fragment bytes per FLOP is worth more than instruction placement;
-//   * K/V tiles of 64 keys double-buffered in LDS (register-staged: the global loads of tile t+2 are issued right after the
-//     barrier of tile t and written to LDS at the end of tile t+1);
-//   * swapped QK^T: S^T = K.Q^T with v_mfma_f32_32x32x16_bf16, so a lane holds 16 keys x ONE query per 32-key block:
-//     max / sum are in-register (one v_permlane32_swap per tile), and the un-normalised P converted to bf16 is directly the
-//     B operand of the PV product (accumulator-as-operand k order);
+//     V^T fragment, K/V tile refresh and barrier is amortised over 64 queries (profiles/r2_attention_*.txt: on one SIMD the matrix
+//     pipe and the vector ALU mostly serialise and the LDS -> VGPR fragment traffic is hidden by neither, so halving the fragment
+//     bytes per FLOP is worth more than instruction placement);
+//   * swapped QK^T: S^T = K.Q^T with v_mfma_f32_32x32x16_bf16, so a lane holds 16 keys x ONE query per 32-key block: sums (and the
+//     rare maximum) are in-register, and the un-normalised P converted to bf16 is directly the B operand of the PV product;
 //   * O^T = V^T.P^T: the V^T fragments come from the row-major V tile through ds_read_b64_tr_b16 (hardware transpose);
 //   * K tile XOR-swizzled for conflict-free ds_read_b128, V tile swizzled for the transposed reads;
-//   * exp2 with the softmax scale folded into one fma; DEFERRED rescale: a query's exponent reference only moves when its row
-//     maximum has outgrown it by more than 2^16 (with random scores the exact running max of SOME query of a wave moves in nearly
-//     every tile, and the 64-register rescale of O with it); fp32 sums and output accumulators.
+//   * exp2 with the softmax scale folded into one fma, fp32 sums and output accumulators, plain (unpacked) fp32 vector code: the file
+//     is built with -fno-slp-vectorize (packed fp32 VALU beside MFMAs is slower, MI355X_MICROARCH.md cycle constants).
+// K/V staging, fragment reads and the maximum-free softmax are described at the kernel.
 #include "kernels.h"
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
@@ -34,12 +31,26 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& s, int base) {
     return r;
 }
 
+// attn_wide_kernel:
+//   * K/V tiles by LDS-DMA (global_load_lds_dwordx4, swizzle on the SOURCE address) through a ring of three tile buffers: tile t+2 is
+//     requested at the start of tile t, a counted s_waitcnt vmcnt + ONE raw s_barrier per tile publish tile t+1.  No staging registers,
+//     no ds_write, no address arithmetic beyond one 64-bit add per piece (the register-staged refresh cost 19 % of the kernel);
+//   * LDS fragment reads as inline asm with hand-counted s_waitcnt lgkmcnt (reads the compiler can see make it drain the LDS-DMA with
+//     vmcnt(0) in front of each of them);
+//   * NO row maximum on the common path: P = exp2(s*c - m_ref) is taken against the reference the query already has; softmax does not
+//     depend on the reference, fp32 / bf16 keep their relative precision at any scale, so all that can go wrong is range.  The row sums
+//     are checked against 2^64 once per tile (any P >= 2^64, inf or NaN trips it); then -- and in every first tile -- the wave takes the
+//     classic path: recompute the scores, exact running maximum, rescale of O and l.  With that the 22-deep max3 chain in front of the
+//     exponentials is gone from the steady state (-8 % on its own).
 template <bool MASKED>
-__global__ __launch_bounds__(256, 2) void attn_fast2_kernel(const bf16_t* __restrict__ qkv, int ldq, int inner, const uint8_t* __restrict__ mask,
-                                                            bf16_t* __restrict__ out, int ldo, int N, float c) {
-    constexpr int KT = 64, QB = 2;
-    constexpr int TILE_BYTES = KT * 128;
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+__global__ __launch_bounds__(256, 2) void attn_wide_kernel(const bf16_t* __restrict__ qkv, int ldq, int inner, const uint8_t* __restrict__ mask,
+                                                           bf16_t* __restrict__ out, int ldo, int N, float c) {
+    constexpr int KT = 64, QB = 2, TB = KT * 128, NBUF = 3, BUF = 2 * TB, WAVES = 4;
+    constexpr int PCS = 8 / WAVES;  // K (and V) pieces per wave per tile
+    constexpr int MAXT = 128;  // tiles whose key validity bits fit the LDS table (launcher: N <= 64 * MAXT when masked)
+    __shared__ __attribute__((aligned(1024))) char smem[NBUF * BUF + (MASKED ? MAXT * 8 : 0)];
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NQ = gridDim.x, BH = gridDim.y * gridDim.z;
@@ -50,11 +61,23 @@ __global__ __launch_bounds__(256, 2) void attn_fast2_kernel(const bf16_t* __rest
         qblk = j % NQ;
         bh = (j / NQ) * 8 + xcd;
     }
-    const int b = bh / gridDim.y, head = bh - b * gridDim.y, q0 = qblk * (128 * QB) + wave * (32 * QB);
+    const int b = bh / gridDim.y, head = bh - b * gridDim.y, q0 = qblk * (32 * QB * WAVES) + wave * (32 * QB);
     const int r = lane & 31, h = lane >> 5;
     const bf16_t* base = qkv + (size_t)b * N * ldq + head * 64;
     const bf16_t* kbase = base + inner;
     const bf16_t* vbase = base + 2 * inner;
+    const int nt = (N + KT - 1) / KT;
+
+    // ---- key validity bits of every tile (masked build): one 64-bit word per tile in LDS, written before any DMA is in flight
+    unsigned long long* mbits = reinterpret_cast<unsigned long long*>(smem + NBUF * BUF);
+    if constexpr (MASKED) {
+        for (int i = wave; i < nt; i += WAVES) {
+            const int key = i * KT + lane;
+            const uint8_t m = key < N ? (mask ? mask[(size_t)b * N + key] : (uint8_t)1) : (uint8_t)0;
+            const unsigned long long bits = __ballot(m != 0);
+            if (lane == 0) mbits[i] = bits;
+        }
+    }
 
     bf16x8 qf[QB][4];
 #pragma unroll
@@ -66,37 +89,58 @@ __global__ __launch_bounds__(256, 2) void attn_fast2_kernel(const bf16_t* __rest
         for (int ds = 0; ds < 4; ++ds) qf[j][ds] = *reinterpret_cast<const bf16x8*>(qp + 16 * ds);
     }
 
-    const int srow0 = tid >> 3, scol = tid & 7;
-    bf16x8 kreg[2], vreg[2];
-    uint8_t mreg = 1;
-    auto load_tile = [&](int k0) {
+    // ---- K/V tile -> LDS by DMA: a piece is 8 key rows x 128 B (one wave-instruction, 1 KiB); wave w moves pieces w (and w + 4 in the 4-wave build) of K and of V
+    const int drow = lane >> 3, dchunk = lane & 7;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned ldq2 = (unsigned)ldq * 2u;
+    unsigned kco[PCS], vco[PCS];  // byte offset of this lane's 16-byte chunk inside the key row, K and V swizzles
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int row = k0 + srow0 + 32 * i;
-            if (row >= N) row = N - 1;
-            kreg[i] = *reinterpret_cast<const bf16x8*>(kbase + (size_t)row * ldq + scol * 8);
-            vreg[i] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)row * ldq + scol * 8);
+    for (int pc = 0; pc < PCS; ++pc) {
+        const int row = (wv + WAVES * pc) * 8 + drow;
+        kco[pc] = (unsigned)((dchunk ^ ((row >> 1) & 7)) << 4);
+        vco[pc] = (unsigned)((dchunk ^ (((row >> 1) & 1) << 2)) << 4);
+        if constexpr (!MASKED) {  // whole tiles only: the row offset is lane-constant too
+            kco[pc] += (unsigned)row * ldq2;
+            vco[pc] += (unsigned)row * ldq2;
         }
-        if constexpr (MASKED) {
-            const int key = k0 + lane;
-            mreg = key < N ? (mask ? mask[(size_t)b * N + key] : (uint8_t)1) : (uint8_t)0;
+    }
+    auto dma_tile = [&](int k0, int buf) {
+        const char* kt = reinterpret_cast<const char*>(kbase) + (MASKED ? (size_t)0 : (size_t)k0 * ldq2);  // wave-uniform
+        const char* vt = reinterpret_cast<const char*>(vbase) + (MASKED ? (size_t)0 : (size_t)k0 * ldq2);
+#pragma unroll
+        for (int pc = 0; pc < PCS; ++pc) {
+            const int piece = wv + WAVES * pc;
+            unsigned ko = kco[pc], vo = vco[pc];
+            if constexpr (MASKED) {  // ragged last tile: rows past the sequence re-read its last key (masked out by the validity bits)
+                const unsigned ro = (unsigned)min(k0 + piece * 8 + drow, N - 1) * ldq2;
+                ko += ro;
+                vo += ro;
+            }
+            char* dst = smem + buf * BUF + piece * 1024;
+            __builtin_amdgcn_global_load_lds((gptr_t)(kt + ko), (lptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(vt + vo), (lptr_t)(dst + TB), 16, 0, 0);
         }
     };
-    auto store_tile = [&](int buf) {
-        char* kb = smem + buf * 2 * TILE_BYTES;
-        char* vb = kb + TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = srow0 + 32 * i;
-            *reinterpret_cast<bf16x8*>(kb + row * 128 + ((scol ^ ((row >> 1) & 7)) << 4)) = kreg[i];
-            *reinterpret_cast<bf16x8*>(vb + row * 128 + ((scol ^ (((row >> 1) & 1) << 2)) << 4)) = vreg[i];
-        }
-    };
-    int k_off[4];
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds) k_off[ds] = r * 128 + (((2 * ds + h) ^ ((r >> 1) & 7)) << 4);
-    const int v_row = 4 * h + ((lane & 15) >> 2);
-    const int v_colb = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+
+    // ---- per-lane LDS read addresses (buffer 0; the tile's buffer offset is added per tile)
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    // K fragment of d-slice ds: row r, logical 16-byte chunk 2*ds + h at physical chunk (2*ds + h) ^ ((r >> 1) & 7): the address of slice ds
+    // is the address of slice 0 with bits 5..6 XORed by ds (the tile buffers are 128-byte aligned), so one register carries all four
+    unsigned ka_t = lds0 + r * 128 + ((h ^ ((r >> 1) & 7)) << 4);  // slice 0, buffer of the current tile
+    unsigned va[2];
+    {
+        const int v_row = 4 * h + ((lane & 15) >> 2);
+        const int v_colb = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+        const int sw = ((v_row >> 1) & 1) << 6;
+        va[0] = lds0 + TB + v_row * 128 + (v_colb ^ sw);
+        va[1] = lds0 + TB + v_row * 128 + ((64 + v_colb) ^ sw);
+    }
+    unsigned ka[4];
+#define F5_KREAD(dst, n) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(ka[(n) & 3]), "n"(((n) >> 2) * 32 * 128))
+#define F5_VREAD(dst, s, mb, g) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(va[mb]), "n"((16 * (s) + 8 * (g)) * 128))
+#define F5_LWAIT1(cnt, a) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(cnt))
+#define F5_LWAIT2(cnt, a, b2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b2) : "n"(cnt))
+#define F5_LWAIT4(cnt, a, b2, c2, d) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b2), "+v"(c2), "+v"(d) : "n"(cnt))
 
     f32x16 o_acc[QB][2];
     float m_run[QB], l_run[QB];
@@ -107,49 +151,96 @@ __global__ __launch_bounds__(256, 2) void attn_fast2_kernel(const bf16_t* __rest
 #pragma unroll
         for (int i = 0; i < 16; ++i) o_acc[j][0][i] = o_acc[j][1][i] = 0.f;
     }
+    // ---- prologue: tiles 0 .. NBUF-2 on their way, tile 0 published
+    constexpr int DIST = NBUF - 1;  // tiles requested ahead
+#define F5_VMWAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+    dma_tile(0, 0);
+    if (nt > 1) dma_tile(KT, 1);
+    {
+        const int ahead = min(nt, DIST) - 1;  // tiles requested after tile 0
+        if (ahead == 0) F5_VMWAIT(0);
+        else if (ahead == 1) F5_VMWAIT(2 * PCS);
+        else F5_VMWAIT(4 * PCS);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the validity words
+    __builtin_amdgcn_s_barrier();
 
-    const int nt = (N + KT - 1) / KT;
-    load_tile(0);
-    store_tile(0);
-    unsigned long long vm = ~0ull;
-    if constexpr (MASKED) vm = __ballot(mreg != 0);
-    __syncthreads();
-    if (nt > 1) load_tile(KT);
-
+    constexpr float RANGE_GUARD = 18446744073709551616.0f;  // 2^64: per-lane row sums of one tile at or above this take the classic path
+    int boff = 0, boff2 = DIST * BUF;  // LDS offsets of tile t's buffer and of tile t+DIST's
     for (int t = 0; t < nt; ++t) {
-        const char* kb_lds = smem + (t & 1) * 2 * TILE_BYTES;
-        const char* vb_lds = kb_lds + TILE_BYTES;
+        if (t + DIST < nt) dma_tile((t + DIST) * KT, boff2 / BUF);
+        ka[0] = ka_t;
+        ka[1] = ka_t ^ 32u;
+        ka[2] = ka_t ^ 64u;
+        ka[3] = ka_t ^ 96u;
+
+        // ---- S^T = K . Q^T
+        unsigned long long vmv = ~0ull;  // validity of this tile's 64 keys (the same word in every lane)
+        if constexpr (MASKED) {
+            const unsigned ma = lds0 + NBUF * BUF + 8 * t;
+            asm volatile("ds_read_b64 %0, %1" : "=v"(vmv) : "v"(ma));
+        }
+        bf16x8 kf[4];  // fragments 4..7 reuse the registers of 0..3 as soon as those MFMAs are issued
+        F5_KREAD(kf[0], 0); F5_KREAD(kf[1], 1); F5_KREAD(kf[2], 2); F5_KREAD(kf[3], 3);
         f32x16 s[QB][2];
+        auto qk = [&](auto& kfr, int n) {
 #pragma unroll
-        for (int j = 0; j < QB; ++j)
+            for (int j = 0; j < QB; ++j)
+                s[j][n >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, qf[j][n & 3], (n & 3) ? s[j][n >> 2] : f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        };
+        // scheduling fences pin {wait, two MFMAs, next read} groups: left alone the compiler hoists all eight reads (32 registers) above the MFMAs
+#define F5_FENCE() __builtin_amdgcn_sched_barrier(0)
+        F5_FENCE();
+        F5_LWAIT1(3, kf[0]); qk(kf[0], 0); F5_FENCE(); F5_KREAD(kf[0], 4);
+        F5_LWAIT1(3, kf[1]); qk(kf[1], 1); F5_FENCE(); F5_KREAD(kf[1], 5);
+        F5_LWAIT1(3, kf[2]); qk(kf[2], 2); F5_FENCE(); F5_KREAD(kf[2], 6);
+        F5_LWAIT1(3, kf[3]); qk(kf[3], 3); F5_FENCE(); F5_KREAD(kf[3], 7);
+        F5_LWAIT1(3, kf[0]); qk(kf[0], 4); F5_FENCE();
+        F5_LWAIT1(2, kf[1]); qk(kf[1], 5); F5_FENCE();
+        F5_LWAIT1(1, kf[2]); qk(kf[2], 6); F5_FENCE();
+        F5_LWAIT1(0, kf[3]); qk(kf[3], 7); F5_FENCE();
+        if constexpr (MASKED) F5_LWAIT1(0, vmv);  // ties the validity word to the waits above (it was the oldest read)
+        // V^T fragments of the first PV step fly during the softmax
+        bf16x4 vf[2][2];  // [mb][g]; the fragments of step s+1 reuse the registers as soon as the MFMAs of step s are issued
+        F5_VREAD(vf[0][0], 0, 0, 0); F5_VREAD(vf[0][1], 0, 0, 1); F5_VREAD(vf[1][0], 0, 1, 0); F5_VREAD(vf[1][1], 0, 1, 1);
+
+        auto apply_mask = [&]() {
+            if constexpr (MASKED) {
+                if (__builtin_amdgcn_ballot_w64(vmv != ~0ull) != 0ull) {
+                    const unsigned long long vmh = h ? (vmv >> 4) : vmv;
+#pragma unroll
+                    for (int j = 0; j < QB; ++j)
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) {
+                                const int bit = 32 * kb + (i & 3) + 8 * (i >> 2);
+                                if (!((vmh >> bit) & 1ull)) s[j][kb][i] = -INFINITY;
+                            }
+                }
+            }
+        };
+        apply_mask();
+
+        // ---- softmax numerators.  Common path: against the reference the query already has, no maximum.
+        float rs[QB] = {0.f, 0.f};
+        auto exps = [&](int j) {
+            const float nm = -m_run[j];
+            float ra = 0.f, rb = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) s[j][kb][i] = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int ds = 0; ds < 4; ++ds) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb_lds + kb * 32 * 128 + k_off[ds]);  // one read feeds both query blocks
-#pragma unroll
-                for (int j = 0; j < QB; ++j) s[j][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[j][ds], s[j][kb], 0, 0, 0);
-            }
-        if constexpr (MASKED) {
-            if (vm != ~0ull) {
-                const unsigned long long vmh = h ? (vm >> 4) : vm;
-#pragma unroll
-                for (int j = 0; j < QB; ++j)
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const int bit = 32 * kb + (i & 3) + 8 * (i >> 2);
-                            if (!((vmh >> bit) & 1ull)) s[j][kb][i] = -INFINITY;
-                        }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < QB; ++j) {
+                for (int i = 0; i < 16; i += 2) {
+                    const float x0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][kb][i], c, nm));
+                    const float x1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][kb][i + 1], c, nm));
+                    s[j][kb][i] = x0;
+                    s[j][kb][i + 1] = x1;
+                    ra += x0;
+                    rb += x1;
+                }
+            rs[j] = ra + rb;
+        };
+        auto row_max = [&](int j) {  // scaled maximum of query block j's 64 scores (both half-waves)
             float mx0 = max3_asm(s[j][0][0], s[j][0][1], s[j][0][2]), mx1 = max3_asm(s[j][1][0], s[j][1][1], s[j][1][2]);
 #pragma unroll
             for (int i = 3; i < 15; i += 2) {
@@ -157,75 +248,105 @@ __global__ __launch_bounds__(256, 2) void attn_fast2_kernel(const bf16_t* __rest
                 mx1 = max3_asm(mx1, s[j][1][i], s[j][1][i + 1]);
             }
             mx0 = max3_asm(mx0, mx1, s[j][0][15]);
-            float mt = max3_asm(mx0, s[j][1][15], s[j][1][15]);
-            {
-                const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
-                mt = fmaxf(__uint_as_float(r2[0]), __uint_as_float(r2[1])) * c;
-            }
-            // deferred rescale (see attention_pipe.hip): the reference only moves when the row maximum outgrew it by more than 2^16
-            float alpha = 1.0f;
-            if (__builtin_amdgcn_ballot_w64(mt > m_run[j] + 16.0f) != 0ull) {
-                const float m_new = fmaxf(m_run[j], mt);
-                alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);
+            const float mt = max3_asm(mx0, s[j][1][15], s[j][1][15]);
+            const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+            return fmaxf(__uint_as_float(r2[0]), __uint_as_float(r2[1])) * c;
+        };
+        if (t == 0) {  // first tile of the block: the reference is its exact maximum (O and l are still zero: nothing to rescale);
+                       // -inf (a fully masked tile) leaves the finite start value alone
+            m_run[0] = fmaxf(m_run[0], row_max(0));
+            m_run[1] = fmaxf(m_run[1], row_max(1));
+        }
+        exps(0);
+        exps(1);
+        if (__builtin_amdgcn_ballot_w64(!(rs[0] < RANGE_GUARD) || !(rs[1] < RANGE_GUARD)) != 0ull) {
+            // some numerator left the guarded range (a score 64 log2 units above its query's reference, inf or NaN): classic step.  The
+            // scores were overwritten by the numerators: recompute them (the K tile is still in LDS), move the references to the exact
+            // running maxima, rescale O and l
+            bf16x8 k2;  // cold path: one fragment at a time
+#define F5_REDO(n) F5_KREAD(k2, n); F5_LWAIT1(0, k2); qk(k2, n);
+            F5_REDO(0) F5_REDO(1) F5_REDO(2) F5_REDO(3) F5_REDO(4) F5_REDO(5) F5_REDO(6) F5_REDO(7)
+#undef F5_REDO
+            apply_mask();
+#pragma unroll
+            for (int j = 0; j < QB; ++j) {
+                const float m_new = fmaxf(m_run[j], row_max(j));
+                const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);
                 m_run[j] = m_new;
+                l_run[j] *= alpha;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     o_acc[j][0][i] *= alpha;
                     o_acc[j][1][i] *= alpha;
                 }
+                exps(j);
             }
-            const float m_new = m_run[j];
-            const f32x2 c2 = {c, c}, nm2 = {-m_new, -m_new};
-            f32x2 rs2 = {0.f, 0.f};
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int i = 0; i < 16; i += 2) {
-                    f32x2 x = __builtin_elementwise_fma(f32x2{s[j][kb][i], s[j][kb][i + 1]}, c2, nm2);
-                    x[0] = __builtin_amdgcn_exp2f(x[0]);
-                    x[1] = __builtin_amdgcn_exp2f(x[1]);
-                    s[j][kb][i] = x[0];
-                    s[j][kb][i + 1] = x[1];
-                    rs2 += x;
-                }
-            const float rs = rs2[0] + rs2[1];
-            l_run[j] = l_run[j] * alpha + rs;
         }
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 pf[QB];
-#pragma unroll
-                for (int j = 0; j < QB; ++j) pf[j] = pack8(s[j][kb], 8 * ks);
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb) {
-                    bf16x8 vf;  // one transposed read pair feeds both query blocks
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        const int row = 32 * kb + 16 * ks + 8 * g + v_row;
-                        const int colb = (64 * mb + v_colb) ^ (((row >> 1) & 1) << 6);
-                        const bf16x4 part = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(vb_lds + row * 128 + colb));
-                        vf[4 * g + 0] = part[0];
-                        vf[4 * g + 1] = part[1];
-                        vf[4 * g + 2] = part[2];
-                        vf[4 * g + 3] = part[3];
-                    }
-#pragma unroll
-                    for (int j = 0; j < QB; ++j) o_acc[j][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[j], o_acc[j][mb], 0, 0, 0);
-                }
-            }
-        if (t + 1 < nt) {
-            store_tile((t + 1) & 1);
-            if constexpr (MASKED) vm = __ballot(mreg != 0);
-        }
-        __syncthreads();
-        if (t + 2 < nt) load_tile((t + 2) * KT);
-    }
+        l_run[0] += rs[0];
+        l_run[1] += rs[1];
 
-    // ---- normalise; stage the wave's 64 x 64 output block through LDS (the K/V buffers are free: the loop ended on a barrier) and store
-    //      whole 128-byte rows: a wave-instruction then writes 8 full lines instead of 8-byte pieces of 32 different rows (the per-lane
-    //      form is store-ISSUE bound: 16 dwordx2 per lane; C2 spends ~15 % of a workgroup's life in that tail, C4 a quarter of that)
+        // ---- O^T += V^T . P^T: four 16-key steps; each half (32 dims) of the V^T fragment is re-requested for the next step right after
+        //      its two MFMAs are issued
+        auto pv_half = [&](int st, int mb, const bf16x8 (&pf)[QB]) {
+            const bf16x8 vfr = __builtin_shufflevector(vf[mb][0], vf[mb][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int j = 0; j < QB; ++j) o_acc[j][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, pf[j], o_acc[j][mb], 0, 0, 0);
+        };
+#define F5_PV(st, more)                                                                       \
+    {                                                                                         \
+        bf16x8 pf[QB];                                                                        \
+        pf[0] = pack8(s[0][(st) >> 1], 8 * ((st) & 1));                                       \
+        pf[1] = pack8(s[1][(st) >> 1], 8 * ((st) & 1));                                       \
+        F5_FENCE();                                                                           \
+        F5_LWAIT2(2, vf[0][0], vf[0][1]);                                                     \
+        pv_half(st, 0, pf);                                                                   \
+        F5_FENCE();                                                                           \
+        if constexpr (more) {                                                                 \
+            F5_VREAD(vf[0][0], (st) + 1, 0, 0);                                               \
+            F5_VREAD(vf[0][1], (st) + 1, 0, 1);                                               \
+        }                                                                                     \
+        F5_LWAIT2((more) ? 2 : 0, vf[1][0], vf[1][1]);                                        \
+        pv_half(st, 1, pf);                                                                   \
+        F5_FENCE();                                                                           \
+        if constexpr (more) {                                                                 \
+            F5_VREAD(vf[1][0], (st) + 1, 1, 0);                                               \
+            F5_VREAD(vf[1][1], (st) + 1, 1, 1);                                               \
+        }                                                                                     \
+    }
+        F5_PV(0, true)
+        F5_PV(1, true)
+        F5_PV(2, true)
+        F5_PV(3, false)
+#undef F5_PV
+
+        // ---- publish tile t+1 (requested a whole tile ago) and retire this tile's buffer: every LDS read of this wave has been waited for
+        {  // tile t+1 must have landed: the tiles requested after it may stay in flight
+            const int ahead = min(nt - 1, t + DIST) - (t + 1);
+            if (ahead <= 0) F5_VMWAIT(0);
+            else if (ahead == 1) F5_VMWAIT(2 * PCS);
+            else F5_VMWAIT(4 * PCS);
+        }
+        __builtin_amdgcn_s_barrier();
+        const int step = boff + BUF == NBUF * BUF ? -(NBUF - 1) * BUF : BUF;  // wave-uniform
+        boff += step;
+        ka_t += step;
+        va[0] += step;
+        va[1] += step;
+        boff2 = boff2 + BUF == NBUF * BUF ? 0 : boff2 + BUF;
+    }
+#undef F5_KREAD
+#undef F5_VREAD
+#undef F5_LWAIT1
+#undef F5_LWAIT4
+#undef F5_VMWAIT
+#undef F5_LWAIT2
+#undef F5_FENCE
+
+    // ---- normalise; stage the wave's 64 x 64 output block through LDS (the ring is free: the loop ended on a barrier with no DMA in flight)
+    //      and store whole 128-byte rows
+    int lane_e = lane;  // laundered: keeps the epilogue's lane-constant addresses from being hoisted above the tile loop (and spilled around it)
+    asm volatile("" : "+v"(lane_e));
+    const int r_e = lane_e & 31, h_e = lane_e >> 5;
     char* stage = smem + wave * (64 * 128);
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
@@ -238,17 +359,15 @@ __global__ __launch_bounds__(256, 2) void attn_fast2_kernel(const bf16_t* __rest
                 bf16x4 v4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)(o_acc[j][mb][4 * g + e] * inv);
-                // row 32*j + r, dims 32*mb + 8*g + 4*h .. +3; 16-byte chunk index XORed with the row so that the 32 rows of a
-                // half-wave spread over the banks
-                const int row = 32 * j + r, chunk = (4 * mb + g) ^ (row & 7);
-                *reinterpret_cast<bf16x4*>(stage + row * 128 + chunk * 16 + 8 * h) = v4;
+                const int row = 32 * j + r_e, chunk = (4 * mb + g) ^ (row & 7);
+                *reinterpret_cast<bf16x4*>(stage + row * 128 + chunk * 16 + 8 * h_e) = v4;
             }
     }
     {
         bf16_t* obase = out + ((size_t)b * N + q0) * ldo + head * 64;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int row = 8 * k + (lane >> 3), chunk = lane & 7;
+            const int row = 8 * k + (lane_e >> 3), chunk = lane_e & 7;
             const u32x4_t v = *reinterpret_cast<const u32x4_t*>(stage + row * 128 + ((chunk ^ (row & 7)) * 16));
             if (q0 + row < N) *reinterpret_cast<u32x4_t*>(obase + (size_t)row * ldo + chunk * 8) = v;
         }
@@ -263,22 +382,24 @@ int launch_attention_pipe(int waves, int B, int N, int H, const void* qkv, int l
 
 int launch_attention_fast(int B, int N, int H, const void* qkv, int ldq, const uint8_t* mask, void* out, int ldo, hipStream_t stream) {
     if ((ldq & 7) || (ldo & 7)) return f5_fail(F5_EINVAL, "attention_fast: ldq and ldo must be multiples of 8");
-    // 256 queries per workgroup need at least one workgroup per CU to pay (C2: 753 vs 705 TFLOP/s, C4: 923 vs 867); below that
-    // (single-utterance serving) the 128-query workgroups of the pipelined kernel fill the chip better (B = 1: 17 vs 25 us)
+    // 256 queries per workgroup need at least one workgroup per CU to pay; below that (single-utterance serving) the 128-query
+    // workgroups of the pipelined kernel fill the chip better (B = 1: 17 vs 23 us)
     static int cus = 0;
     if (cus == 0) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
-    const bool wide = g_attn_variant == 2 || (g_attn_variant == 0 && (long)B * H * cdiv(N, 256) >= cus);
+    const bool masked = mask != nullptr || (N % 64) != 0;
+    bool wide = g_attn_variant == 2 || (g_attn_variant == 0 && (long)B * H * cdiv(N, 256) >= cus);
+    if (masked && N > 64 * 128) wide = false;  // the wide kernel's table of key validity bits holds 128 tiles
+    if ((size_t)N * (size_t)ldq * 2u >= (1ull << 32)) wide = false;  // its per-lane key offsets are 32-bit
     if (!wide) return launch_attention_pipe(4, B, N, H, qkv, ldq, mask, out, ldo, stream);
     const float c = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
-    const bool masked = mask != nullptr || (N % 64) != 0;
-    dim3 grid2(cdiv(N, 256), H, B);
+    dim3 grid(cdiv(N, 256), H, B);
     if (masked)
-        hipLaunchKernelGGL((attn_fast2_kernel<true>), grid2, dim3(256), 0, stream, (const bf16_t*)qkv, ldq, H * 64, mask, (bf16_t*)out, ldo, N, c);
+        hipLaunchKernelGGL((attn_wide_kernel<true>), grid, dim3(256), 0, stream, (const bf16_t*)qkv, ldq, H * 64, mask, (bf16_t*)out, ldo, N, c);
     else
-        hipLaunchKernelGGL((attn_fast2_kernel<false>), grid2, dim3(256), 0, stream, (const bf16_t*)qkv, ldq, H * 64, mask, (bf16_t*)out, ldo, N, c);
+        hipLaunchKernelGGL((attn_wide_kernel<false>), grid, dim3(256), 0, stream, (const bf16_t*)qkv, ldq, H * 64, mask, (bf16_t*)out, ldo, N, c);
     F5_LAUNCH_CHECK();
     return 0;
 }

@@ -278,8 +278,9 @@ def test_attention_long_sequence_spiked_scores(variant):
 
 @pytest.mark.parametrize("variant", [2, 5])
 def test_attention_deferred_rescale_thresholds(variant):
-    """The deferred rescale (a row's exponent reference moves only when its maximum outgrew it by more than 2^16): score jumps just below
-    and far above the threshold, early and late, and a row whose maximum keeps creeping up tile by tile -- against the fp64 softmax."""
+    """Exponent-reference handling of both schedules (pipelined kernel: the reference moves only when a row maximum outgrew it by more
+    than 2^16; 64-queries-per-wave kernel: no maximum unless a row sum leaves the guarded range): score jumps just below and far above
+    the 2^16 threshold, early and late, and a row whose maximum keeps creeping up tile by tile -- against the fp64 softmax."""
     import gpu_helpers as G
     from eraxvif5tts_amd import _lib
     g = torch.Generator().manual_seed(9)
@@ -303,6 +304,52 @@ def test_attention_deferred_rescale_thresholds(variant):
     assert rel_l2(out, ref) < 6e-3
     for q in (5, 37, 90, 200, 300):
         assert (out[0, q] - ref[0, q]).abs().max() < 0.03 * max(1.0, float(ref[0, q].abs().max())), q
+
+
+@pytest.mark.parametrize("masked", [False, True], ids=["unmasked", "leading_keys_masked"])
+def test_attention_wide_kernel_range_guard(masked):
+    """The 64-queries-per-wave kernel takes no row maximum on its common path: numerators are formed against the reference a query already
+    has and the per-tile row sums are checked against 2^64; past that (or inf / NaN) the wave redoes the tile the classic way.  Score
+    jumps just below the guard (62 log2 units: P up to 2^62 stays on the common path), just above it, far above it (exp2 overflows to
+    inf), early and late in the sequence, a query whose maximum creeps up tile by tile, and -- masked -- an utterance whose whole first
+    tile is masked out (its queries enter the second tile with the finite start reference), against the fp64 softmax."""
+    import gpu_helpers as G
+    from eraxvif5tts_amd import _lib
+    g = torch.Generator().manual_seed(21)
+    B, N, H = 2, 1024, 2
+    qkv = torch.randn(B, N, 3, H, 64, generator=g) * 0.5
+    LOG2E = 1.4426950408889634
+    jumps = {5: (700, 62.0 / LOG2E), 37: (130, 65.5 / LOG2E), 90: (1000, 144.0 / LOG2E), 200: (3, 430.0 / LOG2E), 411: (200, 90.0 / LOG2E),
+             600: (90, 63.5 / LOG2E), 777: (960, 64.5 / LOG2E)}
+    for bb in range(B):
+        qn = qkv[bb, :, 0] / qkv[bb, :, 0].norm(dim=-1, keepdim=True)
+        for q, (key, nat) in jumps.items():
+            qkv[bb, q, 0] = qn[q] * 8.0          # |q| = 8: q.k / 8 = |k| cos
+            qkv[bb, key, 1] = qn[q] * nat        # score of (q, key) = nat nats
+        qkv[bb, 300, 0] = qn[300] * 8.0
+        for i, key in enumerate(range(74, 1024, 64)):   # one key per tile, each 6 nats above the previous
+            qkv[bb, key, 1] = qn[300] * (6.0 * (i + 1))
+    qkv = G.bf16_round(qkv)
+    mask = None
+    if masked:
+        mask = torch.ones(B, N, dtype=torch.bool)
+        mask[1, :70] = False      # the first tile (and 6 keys of the second) of utterance 1
+        mask[1, 1000:] = False
+        mask[0, 990:] = False
+    ref = _attn_ref(qkv, mask)
+    _lib.check(_lib.load().f5_tuning_set(b"attn_variant", 2))
+    try:
+        out = G.op_attention(P_BF16, 1, qkv, mask)
+    finally:
+        _lib.check(_lib.load().f5_tuning_set(b"attn_variant", 0))
+    assert torch.isfinite(out).all()
+    if mask is None:
+        assert rel_l2(out, ref) < 6e-3
+    else:  # masked QUERIES are computed and dropped downstream; compare the valid ones
+        assert rel_l2(out[mask], ref[mask]) < 6e-3
+    for bb in range(B):
+        for q in list(jumps) + [300]:
+            assert (out[bb, q] - ref[bb, q]).abs().max() < 0.03 * max(1.0, float(ref[bb, q].abs().max())), (bb, q)
 
 
 def test_attention_tuned_kernel_spiked_scores():
