@@ -10,7 +10,7 @@
 //   * schedules (template VAR): 1 = the two waves of a SIMD staggered by one barrier interval (one feeds the matrix pipe while
 //     the other issues DMA and reads fragments); 30 = the same on a PERSISTENT grid (one workgroup per CU walks tiles, the DMA
 //     front crosses into the next tile under the epilogue) -- the production schedule for whole-tile block linears;
-//     0 = plain ring (narrow tiles).  Measured alternatives (paired / split DMA issue, half-slab ring, store flavours, a 4-wave
+//     0 = plain ring (64-wide tiles; the 128-wide tile runs schedule 1: FF2 at M = 8192 44.6 -> 41.5 us, the 64-wide one gains nothing).  Measured alternatives (paired / split DMA issue, half-slab ring, store flavours, a 4-wave
 //     128x128-per-wave kernel) and the timing-only ablation builds are recorded in DESIGN.md and profiles/r1_06..r1_10; their code
 //     left the library in round 2 (git history: 6761115);
 //   * every accumulator starts from its feature's bias (identical fp32 sums in every variant and tile width); whole tiles take
@@ -612,6 +612,8 @@ template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmPa
                                    0, stream, p, tiles_n, nblocks);
         } else
             hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 1, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
+    } else if (BN == 128 && g_gemm_variant != 0) {  // staggered wave groups pay on the 128-wide tile too (M = 8192: FF2 44.6 -> 41.5 us, out-projection 26.3 -> 24.4 us)
+        hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 1, 5>), grid, block, 0, stream, p, tiles_n, nblocks);
     } else {
         hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 0, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
     }
