@@ -256,6 +256,27 @@ def test_attention_tuned_kernel_long_sequences(variant, N, masked):
     assert (out[valid] - ref[valid]).abs().max() < 0.05
 
 
+@pytest.mark.parametrize("masked", [False, True], ids=["unmasked", "ragged_lens"])
+def test_attention_beyond_the_validity_table(masked):
+    """N = 8320 = 130 key tiles: past the 128-tile table of key validity bits the wide kernel keeps in LDS.  Unmasked (whole tiles) it still
+    runs; with a mask the launcher must hand the call to the pipelined kernel.  One head, against the fp64 softmax."""
+    import gpu_helpers as G
+    from eraxvif5tts_amd import _lib
+    B, N, H = 1, 8320, 1
+    g = torch.Generator().manual_seed(4)
+    qkv = G.bf16_round(torch.randn(B, N, 3, H, 64, generator=g) * 1.5)
+    mask = (torch.arange(N)[None, :] < torch.tensor([N - 301])[:, None]) if masked else None
+    ref = _attn_ref(qkv, mask)
+    _lib.check(_lib.load().f5_tuning_set(b"attn_variant", 2))
+    try:
+        out = G.op_attention(P_BF16, 1, qkv, mask)
+    finally:
+        _lib.check(_lib.load().f5_tuning_set(b"attn_variant", 0))
+    valid = slice(None) if mask is None else mask
+    assert torch.isfinite(out).all()
+    assert rel_l2(out[valid], ref[valid]) < 6e-3
+
+
 @pytest.mark.parametrize("variant", [0, 2, 5])
 def test_attention_long_sequence_spiked_scores(variant):
     """online-softmax rescale path of every schedule at N = 4096: the running max jumps late (key 3900) and in the first tile."""
