@@ -237,20 +237,27 @@ def lens_to_mask(lens, length=None):
 
 
 def sample(W, cfg, cond, text, duration, *, lens=None, steps=32, cfg_strength=1.0, sway_sampling_coef=None,
-           seed=None, max_duration=4096, y0=None, method="euler", no_ref_audio=False, return_trajectory=True):
+           seed=None, max_duration=4096, y0=None, method="euler", no_ref_audio=False, return_trajectory=True,
+           duplicate_test=False, t_inter=0.1, edit_mask=None):
     """cfm.py:82-208 with cond given as mel [b, nc, 100] and text as id tensor [b, nt] (-1 padded).
 
-    ``y0`` (zero-padded [b, N, 100]) overrides the per-sample ``manual_seed(seed); randn`` of cfm.py:178-183.
+    ``y0`` (zero-padded [b, N, 100]) overrides the per-sample ``manual_seed(seed); randn`` of cfm.py:178-183 (the duplicate-test blend of
+    cfm.py:187-190 is applied to it either way).  ``edit_mask`` [b, nc] bool: cfm.py:123-125 (speech editing);
+    ``duplicate_test`` / ``t_inter``: cfm.py:137-139, 185-191.
     """
     cond = cond.float()
     b, nc, nmel = cond.shape
     if lens is None:
         lens = torch.full((b,), nc, dtype=torch.long)
     cond_mask = lens_to_mask(lens)
+    if edit_mask is not None:
+        cond_mask = cond_mask & edit_mask
     if isinstance(duration, int):
         duration = torch.full((b,), duration, dtype=torch.long)
     duration = torch.maximum(torch.maximum((text != -1).sum(dim=-1), lens) + 1, duration).clamp(max=max_duration)
     N = int(duration.max())
+    if duplicate_test:
+        test_cond = F.pad(cond, (0, 0, nc, N - 2 * nc), value=0.0)
     cond = F.pad(cond, (0, 0, 0, N - nc), value=0.0)
     if no_ref_audio:
         cond = torch.zeros_like(cond)
@@ -276,7 +283,12 @@ def sample(W, cfg, cond, text, duration, *, lens=None, steps=32, cfg_strength=1.
         null = dit_forward(W, cfg, x, step_cond, text, t, True, True, mask=mask, text_embed=te_u)
         return pred + (pred - null) * cfg_strength
 
-    t = time_grid(steps, sway_sampling_coef)
+    t_start = 0.0
+    if duplicate_test:
+        t_start = t_inter
+        y0 = (1 - t_start) * y0 + t_start * test_cond
+        steps = int(steps * (1 - t_start))
+    t = time_grid(steps, sway_sampling_coef, t_start=t_start)
     y = y0
     traj = [y0]
     for t0, t1 in zip(t[:-1], t[1:]):  # torchdiffeq fixed grid (a7)

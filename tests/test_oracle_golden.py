@@ -39,6 +39,39 @@ def test_forward_stage_traces(name, branch):
         assert rel_l2(trace[key], z[f"{branch}.{key}"]) < TOL, key
 
 
+OPTION_CASES = {"no_ref": dict(no_ref_audio=True), "dup": dict(duplicate_test=True), "edit": dict(use_edit_mask=True), "nolens": dict(int_duration=True)}
+
+
+def option_kwargs(z, tag, as_cuda=False):
+    """keyword arguments of one tiny_options.npz case for cpu_ref.sample / CFM.sample (same names in both)."""
+    dev = (lambda t: t.cuda()) if as_cuda else (lambda t: t)
+    o = OPTION_CASES[tag]
+    kw = dict(steps=int(z["steps"]), cfg_strength=float(z["cfg_strength"]), sway_sampling_coef=float(z["sway"]))
+    if o.get("int_duration"):
+        kw["duration"] = int(z["int_duration"])
+    else:
+        kw["duration"], kw["lens"] = dev(torch.from_numpy(z["duration"])), dev(torch.from_numpy(z["lens"]))
+    if o.get("no_ref_audio"):
+        kw["no_ref_audio"] = True
+    if o.get("duplicate_test"):
+        kw["duplicate_test"], kw["t_inter"] = True, float(z["t_inter"])
+    if o.get("use_edit_mask"):
+        kw["edit_mask"] = dev(torch.from_numpy(z["edit_mask"]))
+    return kw
+
+
+@pytest.mark.parametrize("tag", list(OPTION_CASES))
+def test_sample_options(tag):
+    """The remaining switches of CFM.sample (cfm.py:123-125 edit_mask, 137-143 duplicate_test / no_ref_audio, 185-191 t_inter, lens=None with
+    an integer duration) against the reference's own outputs on the tiny_base network."""
+    z, zb = load_golden("tiny_options"), load_golden("tiny_base")
+    cfg, W = golden_arch(zb), golden_weights(zb)
+    out, traj = cpu_ref.sample(W, cfg, torch.from_numpy(z["cond"]), torch.from_numpy(z["text"]), seed=int(z["seed"]), **option_kwargs(z, tag))
+    assert traj.shape == z["traj_" + tag].shape
+    assert rel_l2(traj, z["traj_" + tag]) < TOL
+    assert rel_l2(out, z["out_" + tag]) < TOL
+
+
 def test_b1_midpoint_and_cfg0():
     z = load_golden("tiny_b1_midpoint")
     cfg, W = golden_arch(z), golden_weights(z)
