@@ -76,6 +76,7 @@ struct f5_plan_s {
     int gemm_kernel = -1, attn_kernel = -1;  // -1 = auto (tuned kernel when it supports the problem)
     std::map<std::string, float*> taps;
     std::vector<float> mod_tv;  // evaluation times the AdaLN rows in `mod` were computed for (empty = stale); see f5_sample
+    hipStream_t mod_stream = nullptr;  // ... and the stream they were computed on (a call on another stream recomputes them)
     std::vector<GraphEntry> graphs;
     hipStream_t cap_stream = nullptr;  // capture happens on a private stream (the caller's may be the legacy null stream)
     // in-situ timing of the block kernels: HIP event pairs around every launch of an eager sample() (f5_plan_timing_*)
@@ -814,11 +815,12 @@ extern "C" int f5_sample(f5_plan_t p, int B, int N, const float* cond, const int
     // stage inputs into plan-owned buffers (graph nodes have fixed addresses)
     // The time MLP and every AdaLN row depend only on the evaluation times: a server calls sample() with the same grid every time,
     // so the 0.56 GB weight pass is done once per grid and kept (1.7 ms per call; 3 % of a single-utterance sample()).
-    if (p->mod_tv != tv) {
+    if (p->mod_tv != tv || p->mod_stream != st) {  // the rows are ordered only behind the stream they were computed on
         p->mod_tv.clear();
         F5_TRY(launch_set_floats(p->tvals, tv.data(), nev, st));
         F5_TRY(compute_modulation(p, p->tvals, nev, st));
         p->mod_tv = tv;
+        p->mod_stream = st;
     }
     F5_TRY(launch_set_floats(p->coefs, cf.data(), nev, st));
     F5_HIP(hipMemcpyAsync(p->cond_in, cond, state * sizeof(float), hipMemcpyDeviceToDevice, st));
