@@ -353,12 +353,13 @@ def main():
             _lib.check(lib.f5_plan_timing_site(plan, i, C.byref(a), C.byref(n)), "timing_site")
             return a.value, n.value
         es = 2 if args.precision == "bf16" else 4
+        xs = es  # storage bytes of a residual-stream element: fp16 in the bf16 production mode (blocks 1..21 of 22; the first reads fp32), fp32 otherwise
         work = {  # algorithmic work per launch: FLOP for the MFMA-bound kernels, bytes for the HBM-bound LayerNorm passes
             "qkv": ("mfma", flops_qkv), "attention": ("mfma", 4.0 * rows * N * inner), "attn_out": ("mfma", 2.0 * rows * D * inner),
             "ff1": ("mfma", 2.0 * rows * ff * D), "ff2": ("mfma", 2.0 * rows * D * ff), "conv31": ("mfma", 2.0 * rows * D * 64 * 31),
             "input_proj": ("mfma", 2.0 * rows * D * 100),
-            "ln1": ("hbm", rows * D * (4 + es + es)),               # read x (f32) + the FF branch, write the normalised rows
-            "ln2": ("hbm", rows * D * (4 + es + es + 4 + es)),      # read x + both branches, write x and the normalised rows
+            "ln1": ("hbm", rows * D * (xs + es + es)),              # read x + the FF branch, write the normalised rows
+            "ln2": ("hbm", rows * D * (xs + es + es + xs + es)),    # read x + both branches, write x and the normalised rows
         }
         kernels = []
         for i, name in enumerate(_lib.SITES):

@@ -13,14 +13,37 @@
 // FULL: dim == MAXV * 256 (every lane owns MAXV whole vectors): no per-vector bounds branch, so ALL loads of a row (x, y, y2 and the
 // modulation vectors) are issued before the first use -- with the branches the compiler emitted one dependent memory round trip
 // per vector column (4 per row and pass).
-template <typename TO, int MAXV, int YMODE, bool FULL>
-__global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, int ldx, int rows, int dim, const TO* __restrict__ y, int ldy,
-                                                        const TO* __restrict__ y2, const float* __restrict__ mul, const float* __restrict__ add,
+// XI / XO: storage type of the residual stream read / written (float, or _Float16 in the bf16 production mode: the reference's own GPU
+// path keeps the whole residual stream in fp16, utils_infer.py:184-193; fp32 arithmetic here either way, the fp16 store saturates).
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <typename XT> __device__ __forceinline__ f32x4 load_res4(const XT* p) {
+    if constexpr (sizeof(XT) == 2) {
+        const f16x4 r = *reinterpret_cast<const f16x4*>(p);
+        return f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+    } else {
+        return *reinterpret_cast<const f32x4*>(p);
+    }
+}
+template <typename XT> __device__ __forceinline__ void store_res4(XT* p, const f32x4& v) {
+    if constexpr (sizeof(XT) == 2) {
+        f16x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = (_Float16)__builtin_amdgcn_fmed3f(v[e], -65504.0f, 65504.0f);
+        *reinterpret_cast<f16x4*>(p) = r;
+    } else {
+        *reinterpret_cast<f32x4*>(p) = v;
+    }
+}
+
+template <typename TO, int MAXV, int YMODE, bool FULL, typename XI = float, typename XO = float>
+__global__ __launch_bounds__(256) void layernorm_kernel(const XI* x, XO* xo /* may be x itself */, int ldx, int rows, int dim, const TO* __restrict__ y,
+                                                        int ldy, const TO* __restrict__ y2, const float* __restrict__ mul, const float* __restrict__ add,
                                                         int mod_bstride, int rows_per_batch, float add_one, TO* __restrict__ out, int ldo) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    float* xr = x + (size_t)row * ldx;
+    const XI* xr = x + (size_t)row * ldx;
+    [[maybe_unused]] XO* xw = xo + (size_t)row * ldx;
     const int nvec = dim >> 2;  // dim % 4 == 0
     typedef typename std::conditional<sizeof(TO) == 2, bf16x4, f32x4>::type yvec_t;
     auto widen = [](const yvec_t& r) {
@@ -37,7 +60,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, i
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + i * 64;
         if (FULL || c < nvec) {
-            v[i] = *reinterpret_cast<const f32x4*>(xr + c * 4);
+            v[i] = load_res4<XI>(xr + c * 4);
             if constexpr (YMODE != 0) yr[i] = *reinterpret_cast<const yvec_t*>(y + (size_t)row * ldy + c * 4);
             if constexpr (YMODE == 3) yr2[i] = *reinterpret_cast<const yvec_t*>(y2 + (size_t)row * ldy + c * 4);
         }
@@ -58,7 +81,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, i
             if constexpr (YMODE != 0) {
                 v[i] += widen(yr[i]);
                 if constexpr (YMODE == 3) v[i] += widen(yr2[i]);
-                if constexpr (YMODE != 2) *reinterpret_cast<f32x4*>(xr + c * 4) = v[i];
+                if constexpr (YMODE != 2) store_res4<XO>(xw + c * 4, v[i]);
             }
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
@@ -94,18 +117,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, i
     }
 }
 
-template <typename TO, int MAXV>
-static void ln_launch(float* x, int ldx, int rows, int dim, const void* y, int ldy, const void* y2, int ymode, const float* mul, const float* add,
-                      int mod_bstride, int rows_per_batch, float one, void* out, int ldo, hipStream_t stream) {
+template <typename TO, int MAXV, typename XI = float, typename XO = float>
+static void ln_launch(const void* x, void* xo, int ldx, int rows, int dim, const void* y, int ldy, const void* y2, int ymode, const float* mul,
+                      const float* add, int mod_bstride, int rows_per_batch, float one, void* out, int ldo, hipStream_t stream) {
     dim3 grid(cdiv(rows, 4)), block(256);
 #define F5_LN_CASE(M)                                                                                                                        \
     do {                                                                                                                                     \
         if (dim == MAXV * 256)                                                                                                               \
-            hipLaunchKernelGGL((layernorm_kernel<TO, MAXV, M, true>), grid, block, 0, stream, x, ldx, rows, dim, (const TO*)y, ldy, (const TO*)y2, \
-                               mul, add, mod_bstride, rows_per_batch, one, (TO*)out, ldo);                                                   \
+            hipLaunchKernelGGL((layernorm_kernel<TO, MAXV, M, true, XI, XO>), grid, block, 0, stream, (const XI*)x, (XO*)xo, ldx, rows, dim, \
+                               (const TO*)y, ldy, (const TO*)y2, mul, add, mod_bstride, rows_per_batch, one, (TO*)out, ldo);                 \
         else                                                                                                                                 \
-            hipLaunchKernelGGL((layernorm_kernel<TO, MAXV, M, false>), grid, block, 0, stream, x, ldx, rows, dim, (const TO*)y, ldy, (const TO*)y2, \
-                               mul, add, mod_bstride, rows_per_batch, one, (TO*)out, ldo);                                                   \
+            hipLaunchKernelGGL((layernorm_kernel<TO, MAXV, M, false, XI, XO>), grid, block, 0, stream, (const XI*)x, (XO*)xo, ldx, rows, dim, \
+                               (const TO*)y, ldy, (const TO*)y2, mul, add, mod_bstride, rows_per_batch, one, (TO*)out, ldo);                 \
     } while (0)
     if (ymode == 0) F5_LN_CASE(0);
     else if (ymode == 1) F5_LN_CASE(1);
@@ -114,30 +137,48 @@ static void ln_launch(float* x, int ldx, int rows, int dim, const void* y, int l
 #undef F5_LN_CASE
 }
 
-// ymode (see layernorm_kernel): 1 = x += y (written back), 2 = normalise x + y without writing x, 3 = x = (x + y) + y2 (written back)
-int launch_layernorm_add2(int precision_out, float* x, int ldx, int rows, int dim, const void* y, int ldy, const void* y2, int ymode,
-                          const float* mul, const float* add, int mod_bstride, int rows_per_batch, int add_one, void* out, int ldo,
-                          hipStream_t stream) {
+// ymode (see layernorm_kernel): 1 = x += y (written back), 2 = normalise x + y without writing x, 3 = x = (x + y) + y2 (written back).
+// The residual stream is read from `xin` (fp32, or fp16 when xin_f16) and -- modes 1 and 3 -- written to `xout` (fp32 / fp16 by xout_f16;
+// the same buffer as xin or another one of the same leading dimension).  fp16 residual storage exists for the bf16 output type only.
+int launch_layernorm_res(int precision_out, const void* xin, int xin_f16, void* xout, int xout_f16, int ldx, int rows, int dim, const void* y, int ldy,
+                         const void* y2, int ymode, const float* mul, const float* add, int mod_bstride, int rows_per_batch, int add_one, void* out,
+                         int ldo, hipStream_t stream) {
     if (rows <= 0) return 0;
     if (dim % 4 != 0 || dim > 2048 || (ldx & 3) || (ldo & 3) || (mod_bstride & 3) || (y && (ldy & 3)))
         return f5_fail(F5_EINVAL, "layernorm: dim=%d unsupported", dim);
     if (!y) ymode = 0;
     if (ymode < 0 || ymode > 3 || (ymode == 3 && !y2)) return f5_fail(F5_EINVAL, "layernorm: bad residual mode %d", ymode);
+    if ((xin_f16 || xout_f16) && precision_out != F5_PREC_BF16) return f5_fail(F5_EINVAL, "layernorm: fp16 residual storage needs the bf16 output type");
+    if (xin_f16 && !xout_f16 && (ymode == 1 || ymode == 3)) return f5_fail(F5_EINVAL, "layernorm: fp16 -> fp32 residual write-back is not built");
     if (rows_per_batch <= 0) rows_per_batch = rows;
     const float one = add_one ? 1.0f : 0.0f;
+#define F5_LN_DIM(TO, XI, XO)                                                                                                                  \
+    do {                                                                                                                                       \
+        if (dim <= 1024)                                                                                                                       \
+            ln_launch<TO, 4, XI, XO>(xin, xout, ldx, rows, dim, y, ldy, y2, ymode, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream); \
+        else                                                                                                                                   \
+            ln_launch<TO, 8, XI, XO>(xin, xout, ldx, rows, dim, y, ldy, y2, ymode, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream); \
+    } while (0)
     if (precision_out == F5_PREC_BF16) {
-        if (dim <= 1024)
-            ln_launch<bf16_t, 4>(x, ldx, rows, dim, y, ldy, y2, ymode, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream);
+        if (xin_f16)
+            F5_LN_DIM(bf16_t, _Float16, _Float16);
+        else if (xout_f16)
+            F5_LN_DIM(bf16_t, float, _Float16);
         else
-            ln_launch<bf16_t, 8>(x, ldx, rows, dim, y, ldy, y2, ymode, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream);
+            F5_LN_DIM(bf16_t, float, float);
     } else {
-        if (dim <= 1024)
-            ln_launch<float, 4>(x, ldx, rows, dim, y, ldy, y2, ymode, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream);
-        else
-            ln_launch<float, 8>(x, ldx, rows, dim, y, ldy, y2, ymode, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream);
+        F5_LN_DIM(float, float, float);
     }
+#undef F5_LN_DIM
     F5_LAUNCH_CHECK();
     return 0;
+}
+
+int launch_layernorm_add2(int precision_out, float* x, int ldx, int rows, int dim, const void* y, int ldy, const void* y2, int ymode,
+                          const float* mul, const float* add, int mod_bstride, int rows_per_batch, int add_one, void* out, int ldo,
+                          hipStream_t stream) {
+    return launch_layernorm_res(precision_out, x, 0, x, 0, ldx, rows, dim, y, ldy, y2, ymode, mul, add, mod_bstride, rows_per_batch, add_one, out, ldo,
+                                stream);
 }
 
 int launch_layernorm_add(int precision_out, float* x, int ldx, int rows, int dim, const void* y, int ldy, const float* mul, const float* add,

@@ -64,6 +64,7 @@ struct f5_plan_s {
     int maxB = 0, maxN = 0, maxE = 0;
     size_t rows_cap = 0;
     DevArena arena;
+    void* xres16 = nullptr;  // residual stream of the bf16 production mode from the first block on: fp16 storage (see dit_eval)
     float *xres = nullptr, *base = nullptr, *vout = nullptr, *mod = nullptr, *temb = nullptr, *tsin = nullptr, *thid = nullptr;
     float *tvals = nullptr, *coefs = nullptr, *te[2] = {nullptr, nullptr}, *grn_scratch = nullptr, *traj = nullptr, *xmid = nullptr;
     float *cond_in = nullptr, *rope = nullptr, *tap_scratch = nullptr;
@@ -384,6 +385,11 @@ extern "C" int f5_plan_create(f5_model_t m, int max_batch, int max_seq, int max_
     int rc = 0;
     do {
         if ((rc = A.alloc_t(&p->xres, rows * D))) break;
+        if (c.precision == F5_PREC_BF16) {
+            uint16_t* h16 = nullptr;
+            if ((rc = A.alloc_t(&h16, rows * D))) break;
+            p->xres16 = h16;
+        }
         if ((rc = A.alloc_t(&p->base, rows * D))) break;
         if ((rc = A.alloc_t(&p->vout, rows * MELP))) break;
         if ((rc = A.alloc(&p->hT, rows * D * es))) break;
@@ -516,6 +522,7 @@ extern "C" int f5_plan_set_tap(f5_plan_t p, const char* stage, float* dst) {
 }
 
 // ----------------------------------------------------------------------------- helpers
+int g_res_f16 = 1;   // tuning knob ("residual_f16"): bf16 production mode keeps the residual stream in fp16 from the first block on (0 = fp32)
 int g_ln_defer = 1;  // tuning knob ("ln_defer"): write the fp32 residual stream once per DiT block (0 = after every LayerNorm pass)
 
 static GemmParams gp_zero() {
@@ -625,15 +632,23 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
     }
 
     const bool defer = p->taps.empty() && g_ln_defer;
+    // Residual stream storage.  fp32 mode, stage taps or ln_defer = 0: fp32 throughout.  bf16 production mode: the input embedding writes
+    // fp32 (EPI_ADD2), the first block's second LayerNorm pass writes the stream as fp16 and every later pass reads / writes fp16 -- the
+    // reference's own GPU path keeps the whole model, residual stream included, in fp16 (utils_infer.py:184-193); arithmetic stays fp32
+    // and the branches stay bf16.  Bytes per block of the two passes: 1 408 -> 1 024 MiB at C2.
+    const bool r16 = defer && P == F5_PREC_BF16 && g_res_f16 && p->xres16 && c.depth > 0;
     for (int l = 0; l < c.depth; ++l) {
         const BlockW& b = m->blocks[l];
         const float* ml = modp + (size_t)l * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp (modules.py:312)
         const std::string tn = "blk" + std::to_string(l);
+        const bool in16 = r16 && l > 0;
+        const void* xin = in16 ? p->xres16 : (const void*)p->xres;
+        void* xout = r16 ? p->xres16 : (void*)p->xres;
         // x += (conv branch | previous block's gated FF output); n1 = LN(x) * (1 + scale_msa) + shift_msa
-        // With no stage tap set, the fp32 residual stream is written once per block: this pass normalises x + y without storing it,
+        // With no stage tap set, the residual stream is written once per block: this pass normalises x + y without storing it,
         // the second LayerNorm of the block repeats the add (same operands, same order: bit-identical) and stores x + y + y_attn.
         F5_TRY(timed(p, F5_SITE_LN1, st, [&] {
-            return launch_layernorm_add2(P, p->xres, D, rows, D, p->yT, D, nullptr, defer ? 2 : 1, ml + D, ml, mod_bstride, N, 1, p->hT, D, st);
+            return launch_layernorm_res(P, xin, in16, xout, r16, D, rows, D, p->yT, D, nullptr, defer ? 2 : 1, ml + D, ml, mod_bstride, N, 1, p->hT, D, st);
         }));
         if (l == 0) F5_TRY(tap_f32(p, "input_embed", p->xres, D, rows, D, st));
         if (l > 0) F5_TRY(tap_f32(p, "blk" + std::to_string(l - 1) + ".out", p->xres, D, rows, D, st));
@@ -684,8 +699,8 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         F5_TRY(timed(p, F5_SITE_OUT, st, [&] { return run_gemm(p, g, GEMM_DENSE, EPI_GATE_T, st); }));
         // x += y; n2 = LN(x) * (1 + scale_mlp) + shift_mlp
         F5_TRY(timed(p, F5_SITE_LN2, st, [&] {
-            return launch_layernorm_add2(P, p->xres, D, rows, D, p->yT, D, defer ? p->yA : nullptr, defer ? 3 : 1, ml + 4 * D, ml + 3 * D, mod_bstride, N, 1,
-                                         p->hT, D, st);
+            return launch_layernorm_res(P, xin, in16, xout, r16, D, rows, D, p->yT, D, defer ? p->yA : nullptr, defer ? 3 : 1, ml + 4 * D, ml + 3 * D,
+                                        mod_bstride, N, 1, p->hT, D, st);
         }));
         g = gp_zero();
         g.A = p->hT; g.lda = D; g.W = b.w_ff1; g.ldw = D; g.M = rows; g.N = ff; g.K = D;
@@ -698,7 +713,9 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         F5_TRY(timed(p, F5_SITE_FF2, st, [&] { return run_gemm(p, g, GEMM_DENSE, EPI_GATE_T, st); }));
     }
     const float* mf = modp + (size_t)c.depth * 6 * D;  // final AdaLN: (scale, shift) (modules.py:333)
-    F5_TRY(launch_layernorm_add(P, p->xres, D, rows, D, p->yT, D, mf, mf + D, mod_bstride, N, 1, p->hT, D, st));
+    // (no stage tap: the stream itself is not needed any more, so the last add is not written back)
+    F5_TRY(launch_layernorm_res(P, r16 ? p->xres16 : (const void*)p->xres, r16, r16 ? p->xres16 : (void*)p->xres, r16, D, rows, D, p->yT, D, nullptr,
+                                defer ? 2 : 1, mf, mf + D, mod_bstride, N, 1, p->hT, D, st));
     F5_TRY(tap_f32(p, "blk" + std::to_string(c.depth - 1) + ".out", p->xres, D, rows, D, st));
     F5_TRY(tap_t(p, "final_norm", p->hT, D, rows, D, st));
     g = gp_zero();

@@ -119,6 +119,38 @@ def test_true_depth_bf16_sampler_stays_within_tolerance_of_fp32_mode():
     assert torch.isfinite(outs["bf16"]).all() and err < 2e-2
 
 
+def test_fp16_residual_stream_against_fp32_residual_stream():
+    """The bf16 production mode stores the residual stream in fp16 from the first block on (the reference's GPU path keeps the whole model
+    in fp16: utils_infer.py:184-193); `residual_f16 = 0` keeps it in fp32.  F5TTS_Base, N = 512, NFE 8, CFG 2: the two against each other
+    and each against the fp32 parity mode; and the same network with its input scaled so that the residual stream runs 300 x larger
+    (fp16's 11-bit mantissa is relative: the deviation must not grow)."""
+    import bench
+    from eraxvif5tts_amd import _lib
+    from eraxvif5tts_amd.model import CFM, DiT
+    B, N = 2, 512
+    cond, text, lens, dur = bench.synth_batch(B, N, "cuda", seed=3)
+    y0 = torch.randn(B, N, 100, generator=torch.Generator().manual_seed(4))
+    n_ref = cond.shape[1]
+    outs = {}
+    for tag, prec, knob in (("fp32", "fp32", 1), ("bf16_res16", "bf16", 1), ("bf16_res32", "bf16", 0)):
+        torch.manual_seed(1234)
+        model = bench.synth_weights(DiT(**bench.BASE_ARCH, text_num_embeds=bench.VOCAB, mel_dim=100, precision=prec), seed=0)
+        cfm = CFM(transformer=model, mel_spec_kwargs={"mel_spec_type": "vocos"}).cuda()
+        _lib.check(_lib.load().f5_tuning_set(b"residual_f16", knob))
+        try:
+            out, _ = cfm.sample(cond=cond, text=text, duration=dur, lens=lens, steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, y0=y0,
+                                return_trajectory=False)
+        finally:
+            _lib.check(_lib.load().f5_tuning_set(b"residual_f16", 1))
+        outs[tag] = out[:, n_ref:].cpu()
+        del cfm, model
+        torch.cuda.empty_cache()
+    e16, e32, ab = rel_l2(outs["bf16_res16"], outs["fp32"]), rel_l2(outs["bf16_res32"], outs["fp32"]), rel_l2(outs["bf16_res16"], outs["bf16_res32"])
+    print(f"vs fp32 mode: fp16 residual {e16:.3e}, fp32 residual {e32:.3e}; against each other {ab:.3e}")
+    assert torch.isfinite(outs["bf16_res16"]).all()
+    assert e16 < 2e-2 and e32 < 2e-2 and e16 < 1.5 * e32 + 1e-3 and ab < 5e-3
+
+
 def test_true_depth_ragged_shapes_match_fp32_mode():
     """F5TTS_Base at shapes where nothing is a tile multiple (3 utterances x 777 frames: 4 662 token rows, key tail of 9, unequal
     durations): ragged GEMM tiles (generic epilogue, clamped operand rows), the ragged last tile of the halo-tile conv kernel, the
