@@ -8,7 +8,7 @@
 // residual branch (gate * (attention | feed-forward) output in the activation dtype): folding the fp32 residual add into
 // this streaming pass keeps the GEMM epilogues store-only and the read-modify-write fully coalesced.
 // YMODE: 0 = x only; 1 = x += y, written back; 2 = (x + y) normalised but x NOT written back (the add is repeated by the next pass);
-//        3 = x = (x + y) + y2, written back.  Modes 2 + 3 alternate inside a DiT block: the fp32 residual stream is written once per
+//        3 = x = (x + y) + y2, written back.  Modes 2 + 3 alternate inside a DiT block: the residual stream is written once per
 //        block instead of twice, with bit-identical sums (same operands, same order).
 // FULL: dim == MAXV * 256 (every lane owns MAXV whole vectors): no per-vector bounds branch, so ALL loads of a row (x, y, y2 and the
 // modulation vectors) are issued before the first use -- with the branches the compiler emitted one dependent memory round trip

@@ -523,7 +523,7 @@ extern "C" int f5_plan_set_tap(f5_plan_t p, const char* stage, float* dst) {
 
 // ----------------------------------------------------------------------------- helpers
 int g_res_f16 = 1;   // tuning knob ("residual_f16"): bf16 production mode keeps the residual stream in fp16 from the first block on (0 = fp32)
-int g_ln_defer = 1;  // tuning knob ("ln_defer"): write the fp32 residual stream once per DiT block (0 = after every LayerNorm pass)
+int g_ln_defer = 1;  // tuning knob ("ln_defer"): write the residual stream once per DiT block (0 = after every LayerNorm pass)
 
 static GemmParams gp_zero() {
     GemmParams g;

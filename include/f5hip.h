@@ -42,7 +42,7 @@ extern "C" {
 #define F5_ENOMEM -6
 
 /* arithmetic of the dense kernels */
-#define F5_PREC_BF16 0 /* bf16 MFMA inputs, fp32 accumulate, fp32 residual stream / ODE state (production) */
+#define F5_PREC_BF16 0 /* bf16 MFMA inputs, fp32 accumulate and arithmetic, fp32 ODE state, residual stream stored as fp16 (production) */
 #define F5_PREC_FP32 1 /* fp32-input MFMA everywhere (debug / parity mode, ~1/16 of the bf16 rate) */
 
 /* ODE solvers of torchdiffeq's fixed-grid family used by cfm.py:197 */
