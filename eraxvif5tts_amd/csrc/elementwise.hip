@@ -174,6 +174,20 @@ int launch_layernorm_res(int precision_out, const void* xin, int xin_f16, void* 
     return 0;
 }
 
+// fp32 -> fp16 (saturating) copy of n elements (n % 4 == 0): the hoisted part of the input embedding, once per sample() and branch
+__global__ __launch_bounds__(256) void f32_to_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, size_t nvec) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) store_res4<_Float16>(dst + i * 4, load_res4<float>(src + i * 4));
+}
+int launch_f32_to_f16(const float* src, void* dst, size_t n, hipStream_t stream) {
+    if (n == 0) return 0;
+    if (n & 3) return f5_fail(F5_EINVAL, "f32_to_f16: n %% 4 != 0");
+    const size_t nvec = n >> 2;
+    const int grid = (int)(nvec / 256 + 1 < 4096 ? nvec / 256 + 1 : 4096);
+    hipLaunchKernelGGL(f32_to_f16_kernel, dim3(grid), dim3(256), 0, stream, src, (_Float16*)dst, nvec);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_layernorm_add2(int precision_out, float* x, int ldx, int rows, int dim, const void* y, int ldy, const void* y2, int ymode,
                           const float* mul, const float* add, int mod_bstride, int rows_per_batch, int add_one, void* out, int ldo,
                           hipStream_t stream) {

@@ -36,6 +36,7 @@ struct GemmParams {
     int ldof;
     const float* addend;  // EPI_ADD2
     int ldadd;
+    int add2_f16;  // EPI_ADD2: `addend` and `out_f` hold fp16 elements (same leading dimensions, in elements): the bf16 mode's residual stream
     const float* gate;  // EPI_RESID: gate[b * gate_bstride + n] or null (=1)
     int gate_bstride;
     int rows_per_batch;      // sequence length N_seq: b(m) = m / rows_per_batch, position = m % rows_per_batch

@@ -83,14 +83,27 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmParams& p, int m, int n
         const bool vec = nvalid == 4 && (p.ldo & 3) == 0;
         store4_t<T>(reinterpret_cast<T*>(p.out_t) + (size_t)m * p.ldo + n, v, vec, nvalid);
     } else if constexpr (EPI == EPI_ADD2) {
-        const float* a = p.addend + (size_t)m * p.ldadd + n;
+        if (p.add2_f16) {  // fp16 addend / fp16 stream (bf16 production mode)
+            const _Float16* a = reinterpret_cast<const _Float16*>(p.addend) + (size_t)m * p.ldadd + n;
+            _Float16* d = reinterpret_cast<_Float16*>(p.out_f) + (size_t)m * p.ldof + n;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (r < nvalid) v[r] += a[r];
-        const bool vect = nvalid == 4 && (p.ldo & 3) == 0;
-        const bool vecf = nvalid == 4 && (p.ldof & 3) == 0;
-        store4_t<T>(reinterpret_cast<T*>(p.out_t) + (size_t)m * p.ldo + n, v, vect, nvalid);
-        store4_t<float>(p.out_f + (size_t)m * p.ldof + n, v, vecf, nvalid);
+            for (int r = 0; r < 4; ++r)
+                if (r < nvalid) {
+                    v[r] += (float)a[r];
+                    d[r] = (_Float16)__builtin_amdgcn_fmed3f(v[r], -65504.0f, 65504.0f);
+                }
+            const bool vect = nvalid == 4 && (p.ldo & 3) == 0;
+            store4_t<T>(reinterpret_cast<T*>(p.out_t) + (size_t)m * p.ldo + n, v, vect, nvalid);
+        } else {
+            const float* a = p.addend + (size_t)m * p.ldadd + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < nvalid) v[r] += a[r];
+            const bool vect = nvalid == 4 && (p.ldo & 3) == 0;
+            const bool vecf = nvalid == 4 && (p.ldof & 3) == 0;
+            store4_t<T>(reinterpret_cast<T*>(p.out_t) + (size_t)m * p.ldo + n, v, vect, nvalid);
+            store4_t<float>(p.out_f + (size_t)m * p.ldof + n, v, vecf, nvalid);
+        }
     } else if constexpr (EPI == EPI_ROPE_T) {
         // x_transformers apply_rotary_pos_emb on adjacent pairs, fp32 math, q and k parts, first rope_heads heads
         const int part = n / p.rope_inner;

@@ -24,6 +24,7 @@
 #include "gemm_tile.h"
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];  // zero-initialised
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 
 template <int BN, int WM, int MODE, int EPI, int VAR, int NS>
 __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(GemmParams p, int tiles_n, int nblocks) {
@@ -246,7 +247,14 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
 #pragma unroll
             for (int jj = 0; jj < JG; ++jj)
 #pragma unroll
-                for (int i = 0; i < NI; ++i) aux[jj][i] = *reinterpret_cast<const f32x4*>(p.addend + (size_t)mrow[jj] * p.ldadd + ncol[i]);
+                for (int i = 0; i < NI; ++i) {
+                    if (p.add2_f16) {
+                        const f16x4_t hv = *reinterpret_cast<const f16x4_t*>(reinterpret_cast<const _Float16*>(p.addend) + (size_t)mrow[jj] * p.ldadd + ncol[i]);
+                        aux[jj][i] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+                    } else {
+                        aux[jj][i] = *reinterpret_cast<const f32x4*>(p.addend + (size_t)mrow[jj] * p.ldadd + ncol[i]);
+                    }
+                }
         } else if constexpr (EPI == EPI_RESID) {
 #pragma unroll
             for (int jj = 0; jj < JG; ++jj) {
@@ -313,7 +321,14 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
                     } else if constexpr (EPI == EPI_ADD2) {
                         if (ok) {
                             *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.out_t) + mr * p.ldo + ncol[i]) = to_bf16x4(vals[i]);
-                            *reinterpret_cast<f32x4*>(p.out_f + mr * p.ldof + ncol[i]) = vals[i];
+                            if (p.add2_f16) {
+                                f16x4_t hv;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) hv[e] = (_Float16)__builtin_amdgcn_fmed3f(vals[i][e], -65504.0f, 65504.0f);
+                                *reinterpret_cast<f16x4_t*>(reinterpret_cast<_Float16*>(p.out_f) + mr * p.ldof + ncol[i]) = hv;
+                            } else {
+                                *reinterpret_cast<f32x4*>(p.out_f + mr * p.ldof + ncol[i]) = vals[i];
+                            }
                         }
                     } else if constexpr (EPI == EPI_RESID) {
                         if (ok && keep[jj]) *reinterpret_cast<f32x4*>(p.out_f + mr * p.ldof + ncol[i]) = vals[i];

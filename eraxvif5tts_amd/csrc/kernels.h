@@ -20,6 +20,7 @@ int launch_layernorm_add(int precision_out, float* x, int ldx, int rows, int dim
 int launch_layernorm_add2(int precision_out, float* x, int ldx, int rows, int dim, const void* y, int ldy, const void* y2, int ymode,
                           const float* mul, const float* add, int mod_bstride, int rows_per_batch, int add_one, void* out, int ldo,
                           hipStream_t stream);
+int launch_f32_to_f16(const float* src, void* dst, size_t n, hipStream_t stream);  // saturating, n % 4 == 0
 // residual stream read from xin (fp32, or fp16 when xin_f16) and, ymode 1 / 3, written to xout (fp32 / fp16): elementwise.hip
 int launch_layernorm_res(int precision_out, const void* xin, int xin_f16, void* xout, int xout_f16, int ldx, int rows, int dim, const void* y, int ldy,
                          const void* y2, int ymode, const float* mul, const float* add, int mod_bstride, int rows_per_batch, int add_one, void* out,

@@ -64,6 +64,7 @@ struct f5_plan_s {
     int maxB = 0, maxN = 0, maxE = 0;
     size_t rows_cap = 0;
     DevArena arena;
+    void* base16 = nullptr;  // fp16 copy of `base` (bf16 production mode: the input embedding adds it and writes the stream as fp16)
     void* xres16 = nullptr;  // residual stream of the bf16 production mode from the first block on: fp16 storage (see dit_eval)
     float *xres = nullptr, *base = nullptr, *vout = nullptr, *mod = nullptr, *temb = nullptr, *tsin = nullptr, *thid = nullptr;
     float *tvals = nullptr, *coefs = nullptr, *te[2] = {nullptr, nullptr}, *grn_scratch = nullptr, *traj = nullptr, *xmid = nullptr;
@@ -389,6 +390,8 @@ extern "C" int f5_plan_create(f5_model_t m, int max_batch, int max_seq, int max_
             uint16_t* h16 = nullptr;
             if ((rc = A.alloc_t(&h16, rows * D))) break;
             p->xres16 = h16;
+            if ((rc = A.alloc_t(&h16, rows * D))) break;
+            p->base16 = h16;
         }
         if ((rc = A.alloc_t(&p->base, rows * D))) break;
         if ((rc = A.alloc_t(&p->vout, rows * MELP))) break;
@@ -604,7 +607,9 @@ static int compute_base(f5_plan_s* p, const float* cond, const int32_t* lens, co
     GemmParams g = gp_zero();
     g.A = ab; g.lda = kct; g.W = m->w_ct; g.ldw = kct; g.M = nb * N; g.N = D; g.K = kct;
     g.bias = m->b_in; g.out_f = p->base + row0 * D; g.ldof = D;
-    return run_gemm(p, g, GEMM_DENSE, EPI_STORE_F32, st);
+    F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_STORE_F32, st));
+    if (p->base16) F5_TRY(launch_f32_to_f16(p->base + row0 * D, (char*)p->base16 + row0 * D * 2, (size_t)nb * N * D, st));
+    return 0;
 }
 
 // one network evaluation over `nb` batch rows (rows = nb*N) whose noisy mel rows are x[xrows, mel] (xrows divides rows);
@@ -620,6 +625,17 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
     g.A = p->xin; g.lda = MELP; g.W = m->w_x; g.ldw = MELP; g.M = rows; g.N = D; g.K = MELP;
     g.a_row_mod = xrows < rows ? xrows : 0;
     g.addend = p->base; g.ldadd = D; g.out_t = p->hT; g.ldo = D; g.out_f = p->xres; g.ldof = D;
+    // Residual stream storage.  fp32 mode, stage taps or ln_defer = 0: fp32 throughout.  bf16 production mode: fp16 from here on (the
+    // hoisted part of the input embedding included) -- the reference's own GPU path keeps the whole model, residual stream included, in
+    // fp16 (utils_infer.py:184-193); arithmetic stays fp32 and the branches stay bf16.  Bytes per block of the two LayerNorm passes:
+    // 1 408 -> 1 024 MiB at C2; of the input embedding 656 -> 400 MiB.
+    const bool defer = p->taps.empty() && g_ln_defer;
+    const bool r16 = defer && P == F5_PREC_BF16 && g_res_f16 && p->xres16 && p->base16;
+    if (r16) {
+        g.addend = reinterpret_cast<const float*>(p->base16);
+        g.out_f = reinterpret_cast<float*>(p->xres16);
+        g.add2_f16 = 1;
+    }
     F5_TRY(timed(p, F5_SITE_INPUT, st, [&] { return run_gemm(p, g, GEMM_DENSE, EPI_ADD2, st); }));
     // x_res = h + mish(conv(mish(conv(h)))): the second conv only STORES its branch (activation dtype); every fp32 residual
     // add of the network is fused into the LayerNorm pass that follows it (coalesced streaming RMW, store-only GEMM epilogues)
@@ -631,17 +647,11 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         F5_TRY(timed(p, F5_SITE_CONV, st, [&] { return run_gemm(p, g, GEMM_CONV31, li == 0 ? EPI_STORE_T : EPI_GATE_T, st); }));
     }
 
-    const bool defer = p->taps.empty() && g_ln_defer;
-    // Residual stream storage.  fp32 mode, stage taps or ln_defer = 0: fp32 throughout.  bf16 production mode: the input embedding writes
-    // fp32 (EPI_ADD2), the first block's second LayerNorm pass writes the stream as fp16 and every later pass reads / writes fp16 -- the
-    // reference's own GPU path keeps the whole model, residual stream included, in fp16 (utils_infer.py:184-193); arithmetic stays fp32
-    // and the branches stay bf16.  Bytes per block of the two passes: 1 408 -> 1 024 MiB at C2.
-    const bool r16 = defer && P == F5_PREC_BF16 && g_res_f16 && p->xres16 && c.depth > 0;
     for (int l = 0; l < c.depth; ++l) {
         const BlockW& b = m->blocks[l];
         const float* ml = modp + (size_t)l * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp (modules.py:312)
         const std::string tn = "blk" + std::to_string(l);
-        const bool in16 = r16 && l > 0;
+        const bool in16 = r16;
         const void* xin = in16 ? p->xres16 : (const void*)p->xres;
         void* xout = r16 ? p->xres16 : (void*)p->xres;
         // x += (conv branch | previous block's gated FF output); n1 = LN(x) * (1 + scale_msa) + shift_msa
