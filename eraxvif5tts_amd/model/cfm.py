@@ -104,7 +104,10 @@ class CFM(nn.Module):
         native = getattr(self.transformer, "native_sample", None)
         if native is not None and edit_mask is None:
             # lens-prefix cond_mask and duration-prefix key mask are rebuilt on the device by the kernels
-            out, trajectory = native(cond, text, lens, duration, y0, t, steps, cfg_strength, method=method, use_mask=mask is not None,
+            # a batch whose durations are all equal has an all-true key mask (cfm.py:152-155 builds it anyway): the kernels' unmasked
+            # forms compute the same thing
+            use_mask = mask is not None and bool((duration != max_dur).any())
+            out, trajectory = native(cond, text, lens, duration, y0, t, steps, cfg_strength, method=method, use_mask=use_mask,
                                      return_trajectory=return_trajectory, use_graph=use_graph)
             out = out.to(step_cond.dtype)
         else:
