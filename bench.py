@@ -329,7 +329,9 @@ def main():
         "config": {"workload": f"{args.workload if (N, B_req) == (wl_N, wl_B) else 'custom'} F5TTS_Base random-init, CFM.sample euler NFE={nfe} "
                                f"CFG={args.cfg:g} sway=-1, {B_total} utterances x seq_len {N} (N_ref={N // 3}), "
                                f"{'split ' + str(B) + ' per GPU' if world > 1 else 'one GPU'}, hipGraph={'off' if args.no_graph else 'on'}",
-                   "global_batch": B_total, "per_gpu_batch": B, "seq_len": N, "nfe": nfe, "parallelism": f"utterance-sharded dp{world}"},
+                   "global_batch": B_total, "per_gpu_batch": B, "seq_len": N, "nfe": nfe, "parallelism": f"utterance-sharded dp{world}",
+                   "key_mask": "all-true (fixed-length utterances): CFM.sample selects the unmasked kernels, same values as the reference's masked path",
+                   "residual_stream": "fp16 storage, fp32 arithmetic" if args.precision == "bf16" else "fp32"},
         "distributed": {"world_size": dist.get_world_size() if world > 1 else 1, "backend": backend, "devices": devices},
     }
 
