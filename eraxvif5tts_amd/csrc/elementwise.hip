@@ -117,6 +117,77 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const XI* x, XO* xo /* m
     }
 }
 
+// The production shape of the bf16 mode (dim = 1024, fp16 residual stream, bf16 branches and output) with 16-byte accesses: a lane owns
+// two runs of 8 consecutive features.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int YMODE>
+__global__ __launch_bounds__(256) void layernorm1024_h_kernel(const _Float16* x, _Float16* xo, int ldx, int rows, const bf16_t* __restrict__ y, int ldy,
+                                                              const bf16_t* __restrict__ y2, const float* __restrict__ mul, const float* __restrict__ add,
+                                                              int mod_bstride, int rows_per_batch, float add_one, bf16_t* __restrict__ out, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const size_t moff = (size_t)(row / rows_per_batch) * mod_bstride;
+    float v[2][8];
+    f16x8 xr[2];
+    [[maybe_unused]] bf16x8 yr[2], yr2[2];
+    f32x4 m4[2][2], a4[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = (lane + i * 64) * 8;
+        xr[i] = *reinterpret_cast<const f16x8*>(x + (size_t)row * ldx + c);
+        if constexpr (YMODE != 0) yr[i] = *reinterpret_cast<const bf16x8*>(y + (size_t)row * ldy + c);
+        if constexpr (YMODE == 3) yr2[i] = *reinterpret_cast<const bf16x8*>(y2 + (size_t)row * ldy + c);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = (lane + i * 64) * 8;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            m4[i][hh] = *reinterpret_cast<const f32x4*>(mul + moff + c + 4 * hh);
+            a4[i][hh] = *reinterpret_cast<const f32x4*>(add + moff + c + 4 * hh);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = (float)xr[i][e];
+            if constexpr (YMODE != 0) t += (float)yr[i][e];
+            if constexpr (YMODE == 3) t += (float)yr2[i][e];
+            v[i][e] = t;
+        }
+        if constexpr (YMODE == 1 || YMODE == 3) {
+            f16x8 w;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = (_Float16)__builtin_amdgcn_fmed3f(v[i][e], -65504.0f, 65504.0f);
+            *reinterpret_cast<f16x8*>(xo + (size_t)row * ldx + (lane + i * 64) * 8) = w;
+        }
+        // the same pairing of the sum as the 4-wide kernel: ((a0 + a1) + (a2 + a3)) per group of four
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        s += (v[i][4] + v[i][5]) + (v[i][6] + v[i][7]);
+    }
+    const float mean = wave_sum(s) / 1024.0f;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = v[i][e] - mean;
+            q += d * d;
+        }
+    const float rstd = rsqrtf(wave_sum(q) / 1024.0f + 1e-6f);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((v[i][e] - mean) * rstd * (add_one + m4[i][e >> 2][e & 3]) + a4[i][e >> 2][e & 3]);
+        *reinterpret_cast<bf16x8*>(out + (size_t)row * ldo + (lane + i * 64) * 8) = o;
+    }
+}
+int g_ln_wide = 1;  // tuning knob ("ln_wide"): 16-byte form of the LayerNorm pass at its production shape
+
 template <typename TO, int MAXV, typename XI = float, typename XO = float>
 static void ln_launch(const void* x, void* xo, int ldx, int rows, int dim, const void* y, int ldy, const void* y2, int ymode, const float* mul,
                       const float* add, int mod_bstride, int rows_per_batch, float one, void* out, int ldo, hipStream_t stream) {
@@ -159,6 +230,19 @@ int launch_layernorm_res(int precision_out, const void* xin, int xin_f16, void* 
         else                                                                                                                                   \
             ln_launch<TO, 8, XI, XO>(xin, xout, ldx, rows, dim, y, ldy, y2, ymode, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream); \
     } while (0)
+    if (precision_out == F5_PREC_BF16 && xin_f16 && xout_f16 && dim == 1024 && g_ln_wide && !(ldx & 7) && !(ldo & 7) && !(y && (ldy & 7))) {
+        dim3 grid(cdiv(rows, 4)), block(256);
+#define F5_LN_W(M)                                                                                                                              \
+    hipLaunchKernelGGL((layernorm1024_h_kernel<M>), grid, block, 0, stream, (const _Float16*)xin, (_Float16*)xout, ldx, rows, (const bf16_t*)y, ldy, \
+                       (const bf16_t*)y2, mul, add, mod_bstride, rows_per_batch, one, (bf16_t*)out, ldo)
+        if (ymode == 0) F5_LN_W(0);
+        else if (ymode == 1) F5_LN_W(1);
+        else if (ymode == 2) F5_LN_W(2);
+        else F5_LN_W(3);
+#undef F5_LN_W
+        F5_LAUNCH_CHECK();
+        return 0;
+    }
     if (precision_out == F5_PREC_BF16) {
         if (xin_f16)
             F5_LN_DIM(bf16_t, _Float16, _Float16);
