@@ -403,6 +403,62 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
             *reinterpret_cast<u32x4*>(o + 32) = q1;
         });
     };
+    // ---- lean form of EPI_ADD2 with the fp16 addend / fp16 stream (the input embedding of the bf16 mode, a purely HBM-bound launch):
+    //      16-byte accesses throughout.  The addend is loaded at the position a lane STORES (8 consecutive features of one of two adjacent
+    //      16-feature tiles) and brought to the accumulator layout by the inverse of pair_swap; both outputs leave through pair_swap.
+    [[maybe_unused]] auto lean_add2_f16 = [&]() __attribute__((always_inline)) {
+        const size_t row0 = (size_t)(m0 + wm * WM + fr);
+        const _Float16* arow = reinterpret_cast<const _Float16*>(p.addend) + row0 * p.ldadd + nwide;
+        _Float16* hrow = reinterpret_cast<_Float16*>(p.out_f) + row0 * p.ldof + nwide;
+        bf16_t* orow = reinterpret_cast<bf16_t*>(p.out_t) + row0 * p.ldo + nwide;
+        u32x4 adA[2], adB[2];  // addends of the even / odd token tile in flight, per feature tile pair (named apart: no runtime-indexed arrays)
+        auto load_add = [&](auto jc, u32x4 (&dst)[2]) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            dst[0] = *reinterpret_cast<const u32x4*>(arow + (size_t)16 * j * p.ldadd);
+            dst[1] = *reinterpret_cast<const u32x4*>(arow + (size_t)16 * j * p.ldadd + 32);
+        };
+        auto widen_h = [](unsigned lo, unsigned hi) __attribute__((always_inline)) {
+            const f16x4_t h = __builtin_bit_cast(f16x4_t, u32x2{lo, hi});
+            return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        };
+        auto to_h = [](const f32x4& v) __attribute__((always_inline)) {
+            f16x4_t h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (_Float16)__builtin_amdgcn_fmed3f(v[e], -65504.0f, 65504.0f);
+            return __builtin_bit_cast(bf16x4, h);  // 8 bytes through pair_swap's bit shuffle
+        };
+        load_add(std::integral_constant<int, 0>{}, adA);
+        static_for<MI>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j + 1 < MI) {
+                if constexpr ((j + 1) & 1)
+                    load_add(std::integral_constant<int, j + 1>{}, adB);
+                else
+                    load_add(std::integral_constant<int, j + 1>{}, adA);
+            }
+            f32x4 v0, v1, v2, v3;
+            {
+                const u32x4 q = (j & 1) ? adB[0] : adA[0];
+                // inverse of pair_swap: {q0, q1} / {q2, q3} are the two halves of this lane's 8 stored features
+                const u32x2 s0 = __builtin_amdgcn_permlane16_swap(q[0], q[2], false, false);
+                const u32x2 s1 = __builtin_amdgcn_permlane16_swap(q[1], q[3], false, false);
+                v0 = acc[0][j] + widen_h(s0[0], s1[0]);
+                v1 = acc[1][j] + widen_h(s0[1], s1[1]);
+            }
+            {
+                const u32x4 q = (j & 1) ? adB[1] : adA[1];
+                const u32x2 s0 = __builtin_amdgcn_permlane16_swap(q[0], q[2], false, false);
+                const u32x2 s1 = __builtin_amdgcn_permlane16_swap(q[1], q[3], false, false);
+                v2 = acc[2][j] + widen_h(s0[0], s1[0]);
+                v3 = acc[3][j] + widen_h(s0[1], s1[1]);
+            }
+            const size_t jo = (size_t)16 * j;
+            *reinterpret_cast<u32x4*>(orow + jo * p.ldo) = pair_swap(to_bf16x4(v0), to_bf16x4(v1));
+            *reinterpret_cast<u32x4*>(orow + jo * p.ldo + 32) = pair_swap(to_bf16x4(v2), to_bf16x4(v3));
+            *reinterpret_cast<u32x4*>(hrow + jo * p.ldof) = pair_swap(to_h(v0), to_h(v1));
+            *reinterpret_cast<u32x4*>(hrow + jo * p.ldof + 32) = pair_swap(to_h(v2), to_h(v3));
+        });
+    };
     // whole tile + the operand forms the lean epilogue assumes; anything else takes the generic path
     [[maybe_unused]] auto lean_ok = [&]() {
         if constexpr (!(EPI == EPI_STORE_T || EPI == EPI_GATE_T || EPI == EPI_ROPE_T)) return false;
@@ -418,6 +474,11 @@ __global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(Gemm
             else
                 lean_epilogue(std::integral_constant<int, ACT_NONE>{});
             return;
+        } else if constexpr (EPI == EPI_ADD2 && NI == 4) {
+            if (p.lean_epi && p.add2_f16 && p.act == ACT_NONE && m0 + BM <= p.M && n0 + BN <= p.N && ((p.ldo | p.ldof | p.ldadd) & 7) == 0) {
+                lean_add2_f16();
+                return;
+            }
         } else if constexpr (EPI == EPI_STORE_T || EPI == EPI_GATE_T || EPI == EPI_ROPE_T) {
             if (p.lean_epi && lean_ok()) {
                 if (p.act == ACT_GELU_TANH)

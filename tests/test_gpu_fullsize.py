@@ -151,6 +151,33 @@ def test_fp16_residual_stream_against_fp32_residual_stream():
     assert e16 < 2e-2 and e32 < 2e-2 and e16 < 1.5 * e32 + 1e-3 and ab < 5e-3
 
 
+def test_lean_and_generic_epilogues_give_the_same_sampler_output():
+    """Whole-tile launches take the lean GEMM epilogues (store-only forms with packed fp32 math and the exp2 form of GELU, and the 16-byte
+    fp16 form of the input embedding's add); `gemm_lean = 0` sends every launch through the generic epilogue.  The two differ only in
+    fp32 rounding before the bf16 / fp16 stores: F5TTS_Base, B = 2, N = 512 (2 048 token rows = whole 256-row tiles), two Euler steps."""
+    import bench
+    from eraxvif5tts_amd import _lib
+    from eraxvif5tts_amd.model import CFM, DiT
+    B, N = 2, 512
+    cond, text, lens, dur = bench.synth_batch(B, N, "cuda", seed=6)
+    y0 = torch.randn(B, N, 100, generator=torch.Generator().manual_seed(7))
+    torch.manual_seed(1234)
+    model = bench.synth_weights(DiT(**bench.BASE_ARCH, text_num_embeds=bench.VOCAB, mel_dim=100, precision="bf16"), seed=0)
+    cfm = CFM(transformer=model, mel_spec_kwargs={"mel_spec_type": "vocos"}).cuda()
+    outs = []
+    for lean in (1, 0):
+        _lib.check(_lib.load().f5_tuning_set(b"gemm_lean", lean))
+        try:
+            out, _ = cfm.sample(cond=cond, text=text, duration=dur, lens=lens, steps=2, cfg_strength=2.0, sway_sampling_coef=-1.0, y0=y0,
+                                return_trajectory=False)
+        finally:
+            _lib.check(_lib.load().f5_tuning_set(b"gemm_lean", 1))
+        outs.append(out.cpu())
+    err = rel_l2(outs[0], outs[1])
+    print(f"lean vs generic epilogues: rel-L2 {err:.3e}")
+    assert torch.isfinite(outs[0]).all() and err < 2e-3
+
+
 def test_true_depth_ragged_shapes_match_fp32_mode():
     """F5TTS_Base at shapes where nothing is a tile multiple (3 utterances x 777 frames: 4 662 token rows, key tail of 9, unequal
     durations): ragged GEMM tiles (generic epilogue, clamped operand rows), the ragged last tile of the halo-tile conv kernel, the
