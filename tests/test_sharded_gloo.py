@@ -1,7 +1,7 @@
 """world_size-2 CPU (gloo) test of the utterance-sharded inference path: contiguous split, no collective inside sampling,
 one all_gather of the finished mels, identical result and order on every rank."""
 import os
-import socket
+import tempfile
 
 import torch
 import torch.distributed as dist
@@ -31,11 +31,13 @@ def _batches():
     return bs
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _worker(rank, world, rendezvous, q):
+    # file rendezvous: no port to race for with other processes of the host
+    dist.init_process_group("gloo", init_method="file://" + rendezvous, rank=rank, world_size=world)
     outs = sample_sharded(_fake_sample, _batches(), device="cpu")
-    q.put((rank, [o.clone() for o in outs]))
+    # plain numpy arrays through the queue: a torch tensor travels as a shared-memory handle that dies with this process if the parent is
+    # slow to pick it up
+    q.put((rank, [o.numpy().copy() for o in outs]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -50,12 +52,10 @@ def test_split_is_contiguous_and_complete():
 
 def test_two_rank_gather_matches_single_process():
     single = sample_sharded(_fake_sample, _batches(), device="cpu")
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    rendezvous = os.path.join(tempfile.mkdtemp(prefix="f5_gloo_"), "store")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, rendezvous, q)) for r in range(2)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=120) for _ in range(2))
@@ -65,4 +65,5 @@ def test_two_rank_gather_matches_single_process():
     for rank in (0, 1):
         assert len(results[rank]) == len(single)
         for a, b in zip(results[rank], single):
+            a = torch.from_numpy(a)
             assert a.shape == b.shape and torch.equal(a, b)
