@@ -39,9 +39,10 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& s, int base) {
 //     vmcnt(0) in front of each of them);
 //   * NO row maximum on the common path: P = exp2(s*c - m_ref) is taken against the reference the query already has; softmax does not
 //     depend on the reference, fp32 / bf16 keep their relative precision at any scale, so all that can go wrong is range.  The row sums
-//     are checked against 2^64 once per tile (any P >= 2^64, inf or NaN trips it); then -- and in every first tile -- the wave takes the
-//     classic path: recompute the scores, exact running maximum, rescale of O and l.  With that the 22-deep max3 chain in front of the
-//     exponentials is gone from the steady state (-8 % on its own).
+//     are checked against 2^64 once per tile (any P >= 2^64, inf or NaN trips it); only then the wave takes the classic step: scores
+//     recomputed from the K tile still in LDS, exact running maximum, rescale of O and l.  The first tile of a block sets the reference
+//     to its exact maximum (nothing to rescale yet).  With that the 22-deep max3 chain in front of the exponentials is gone from the
+//     steady state (-8 % on its own).
 template <bool MASKED>
 __global__ __launch_bounds__(256, 2) void attn_wide_kernel(const bf16_t* __restrict__ qkv, int ldq, int inner, const uint8_t* __restrict__ mask,
                                                            bf16_t* __restrict__ out, int ldo, int N, float c) {
