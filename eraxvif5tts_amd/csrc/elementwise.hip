@@ -123,9 +123,19 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <int YMODE>
 __global__ __launch_bounds__(256) void layernorm1024_h_kernel(const _Float16* x, _Float16* xo, int ldx, int rows, const bf16_t* __restrict__ y, int ldy,
                                                               const bf16_t* __restrict__ y2, const float* __restrict__ mul, const float* __restrict__ add,
-                                                              int mod_bstride, int rows_per_batch, float add_one, bf16_t* __restrict__ out, int ldo) {
+                                                              int mod_bstride, int rows_per_batch, float add_one, bf16_t* __restrict__ out, int ldo,
+                                                              PrefetchSet pf) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // weight prefetch: one dword per 128-byte line is enough to pull the line in; lane l of the wave of row w touches line 64 w + l of every
+    // range (8 KiB of lines per wave and range; the loads are issued first and waited for last)
+    unsigned pfv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        pfv[r] = 0u;
+        const unsigned line = (unsigned)row * 64u + lane;
+        if (pf.p[r] && line * 128u < pf.n[r]) pfv[r] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(pf.p[r]) + (size_t)line * 128);
+    }
     if (row >= rows) return;
     const size_t moff = (size_t)(row / rows_per_batch) * mod_bstride;
     float v[2][8];
@@ -185,6 +195,8 @@ __global__ __launch_bounds__(256) void layernorm1024_h_kernel(const _Float16* x,
         for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((v[i][e] - mean) * rstd * (add_one + m4[i][e >> 2][e & 3]) + a4[i][e >> 2][e & 3]);
         *reinterpret_cast<bf16x8*>(out + (size_t)row * ldo + (lane + i * 64) * 8) = o;
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(pfv[r]));  // keeps the prefetch loads alive
 }
 int g_ln_wide = 1;  // tuning knob ("ln_wide"): 16-byte form of the LayerNorm pass at its production shape
 
@@ -213,7 +225,7 @@ static void ln_launch(const void* x, void* xo, int ldx, int rows, int dim, const
 // the same buffer as xin or another one of the same leading dimension).  fp16 residual storage exists for the bf16 output type only.
 int launch_layernorm_res(int precision_out, const void* xin, int xin_f16, void* xout, int xout_f16, int ldx, int rows, int dim, const void* y, int ldy,
                          const void* y2, int ymode, const float* mul, const float* add, int mod_bstride, int rows_per_batch, int add_one, void* out,
-                         int ldo, hipStream_t stream) {
+                         int ldo, hipStream_t stream, const PrefetchSet* prefetch) {
     if (rows <= 0) return 0;
     if (dim % 4 != 0 || dim > 2048 || (ldx & 3) || (ldo & 3) || (mod_bstride & 3) || (y && (ldy & 3)))
         return f5_fail(F5_EINVAL, "layernorm: dim=%d unsupported", dim);
@@ -232,9 +244,11 @@ int launch_layernorm_res(int precision_out, const void* xin, int xin_f16, void* 
     } while (0)
     if (precision_out == F5_PREC_BF16 && xin_f16 && xout_f16 && dim == 1024 && g_ln_wide && !(ldx & 7) && !(ldo & 7) && !(y && (ldy & 7))) {
         dim3 grid(cdiv(rows, 4)), block(256);
+        PrefetchSet pfs{{nullptr, nullptr, nullptr, nullptr}, {0u, 0u, 0u, 0u}};
+        if (prefetch) pfs = *prefetch;
 #define F5_LN_W(M)                                                                                                                              \
     hipLaunchKernelGGL((layernorm1024_h_kernel<M>), grid, block, 0, stream, (const _Float16*)xin, (_Float16*)xout, ldx, rows, (const bf16_t*)y, ldy, \
-                       (const bf16_t*)y2, mul, add, mod_bstride, rows_per_batch, one, (bf16_t*)out, ldo)
+                       (const bf16_t*)y2, mul, add, mod_bstride, rows_per_batch, one, (bf16_t*)out, ldo, pfs)
         if (ymode == 0) F5_LN_W(0);
         else if (ymode == 1) F5_LN_W(1);
         else if (ymode == 2) F5_LN_W(2);

@@ -351,13 +351,17 @@ extern "C" int f5_bench_mfma_rate(int random_operands, float* tflops, f5_stream_
     return sync_and_release(a, st, rc);
 }
 
-extern int g_gemm_variant, g_gemm_group, g_gemm_persist_grid, g_gemm_persist, g_gemm_lean, g_ln_defer, g_ln_wide, g_res_f16, g_conv31, g_attn_variant, g_vocos_fft;
+extern int g_gemm_variant, g_gemm_group, g_gemm_persist_grid, g_gemm_persist, g_gemm_lean, g_ln_defer, g_ln_wide, g_w_prefetch, g_res_f16, g_conv31, g_attn_variant, g_vocos_fft;
 int g_tuning_epoch = 0;
 extern "C" int f5_tuning_set(const char* key, int value) {
     if (!key) return f5_fail(F5_EINVAL, "null key");
     ++g_tuning_epoch;  // hipGraphs captured by plans under the previous knob values are dropped at their next use (model.hip)
     if (strcmp(key, "gemm_variant") == 0) {
         g_gemm_variant = value;
+        return 0;
+    }
+    if (strcmp(key, "w_prefetch") == 0) {
+        g_w_prefetch = value;
         return 0;
     }
     if (strcmp(key, "ln_wide") == 0) {
