@@ -24,6 +24,9 @@ One JSON line on rank 0 with the driver's contract fields plus
   "cpu_baseline"  the CPU oracle (oracle/cpu_ref.py, plain fp32 torch; the reference itself cannot travel) timed on this
                   host's cores on a bounded sample, scaled linearly to the workload's NFE.
   --workload vocos (C5): Vocos.decode on [B, 100, T] (T = 683 at B = 32, or --seq-len T), frames/s, HBM roofline of the ISTFT head.
+The default C2 run on one GPU also measures C4 (2 timed sample() calls + in-situ kernel table) and C5 afterwards and reports them under
+"workloads": {"C4": {value, ms_per_step, attention_frac, ...}, "C5": {value, rtf, head_gbs, cpu_baseline, ...}} (--no-extra skips them);
+the C2 fields are unchanged.
 """
 from __future__ import annotations
 
@@ -145,32 +148,34 @@ def launch_children(args):
     sys.exit(rc)
 
 
-def bench_vocos(args, dev):
-    """C5: Vocos.decode on the generated part of a C2 (T = 683) or C4 (T = 2731) batch."""
+def bench_vocos(args, dev, T=None, B=None, steps=None, warmup=None):
+    """C5: Vocos.decode on the generated part of a C2 (T = 683) or C4 (T = 2731) batch.  Returns the result record."""
     import torch
     from eraxvif5tts_amd import _lib
     from eraxvif5tts_amd.vocos import Vocos
     from oracle import cpu_ref
     lib = _lib.load()
-    T = args.seq_len if args.seq_len else 683
-    B = args.batch if args.batch else (32 if T <= 1024 else 8)
+    T = T or (args.seq_len if args.seq_len else 683)
+    B = B or (args.batch if args.batch else (32 if T <= 1024 else 8))
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
     V = cpu_ref.random_vocos_weights(seed=3)  # random init of the vocos-mel-24khz shape (no checkpoint offline)
     voc = Vocos()
     voc.load_state_dict({k: t for k, t in V.items() if k in voc.state_dict()}, strict=False)
     voc = voc.to(dev)
     g = torch.Generator().manual_seed(0)
     mel = (torch.randn(B, 100, T, generator=g) * 2 - 3).clamp(math.log(1e-5), 3.0).to(dev)
-    for _ in range(args.warmup):
+    for _ in range(max(warmup, 1)):
         wave = voc.decode(mel)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         wave = voc.decode(mel)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     assert torch.isfinite(wave).all()
-    frames = B * T * args.steps
-    audio_s = B * (T - 1) * 256 / 24000.0 * args.steps
+    frames = B * T * steps
+    audio_s = B * (T - 1) * 256 / 24000.0 * steps
     # ISTFT head alone (HBM-bound): HIP events around f5_vocoder_istft_head on this stream
     head = torch.randn(B, T, 1026, generator=g).to(dev) * 0.5
     hw = voc.istft_head(head)
@@ -186,15 +191,15 @@ def bench_vocos(args, dev):
     achieved = head_bytes / (head_ms * 1e-3) / 1e9
     flops = 2.0 * B * T * (7 * 100 * 512 + 8 * (7 * 512 + 2 * 512 * 1536) + 512 * 1026)
     result = {
-        "metric": "vocoder mel-frames/s", "value": round(frames / elapsed, 2), "unit": "mel-frames/s", "n_gpus": 1, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "metric": "vocoder mel-frames/s", "value": round(frames / elapsed, 2), "unit": "mel-frames/s", "n_gpus": 1, "steps": steps,
+        "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rtf": round(elapsed / audio_s, 7),
         "config": {"workload": f"C5 Vocos.decode (vocos-mel-24khz shape, random init): mel [B={B}, 100, T={T}] -> wave [B, {(T - 1) * 256}]",
                    "global_batch": B, "frames": T},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": None, "kernel": "ISTFT head (exp/clip/cos/sin -> 1024-point inverse FFT in LDS -> window; overlap-add)",
                      "launch": f"{head_bytes / 1e6:.1f} MB algorithmic (5.1 KB per frame) in {head_ms:.4f} ms, mean of {iters} calls (HIP events)",
-                     "backbone_tflops_f32": round(flops * args.steps / elapsed / 1e12, 2), "backbone_peak_f32": MFMA_F32_PEAK_TFLOPS},
+                     "backbone_tflops_f32": round(flops * steps / elapsed / 1e12, 2), "backbone_peak_f32": MFMA_F32_PEAK_TFLOPS},
     }
     if not args.no_cpu_baseline:
         cores = _host_cores()
@@ -205,7 +210,96 @@ def bench_vocos(args, dev):
         dt = time.perf_counter() - t0
         result["cpu_baseline"] = {"value": round(bs * T / dt, 2), "unit": "mel-frames/s", "cores": cores, "kind": "port",
                                   "sample": f"oracle/cpu_ref.vocos_decode fp32 torch, B={bs} T={T} ({dt:.2f} s)"}
-    print(json.dumps(result), flush=True)
+    del voc
+    torch.cuda.empty_cache()
+    return result
+
+
+def insitu_kernels(model, cfm, batch, B, N, nfe, args):
+    """One extra EAGER sample() with a HIP event pair around every block kernel (7 per block + 3 per evaluation) on the stream the kernels
+    run on -- the same launches rocprofv3 averages in profiles/.  Returns (mean ms of the fused QKV GEMM, its launch count, its FLOP per
+    launch, the per-kernel table)."""
+    from eraxvif5tts_amd import _lib
+    lib = _lib.load()
+    cond, text, lens, duration = batch
+    cfg_on = args.cfg >= 1e-5
+    rows = (2 if cfg_on else 1) * B * N
+    inner, D, ff, depth = 16 * 64, 1024, 2048, BASE_ARCH["depth"]
+    plan = model.plan(B, N, nfe)
+    ms, cnt = C.c_float(0.0), C.c_int(0)
+    _lib.check(lib.f5_plan_timing_begin(plan, (7 * depth + 4) * nfe), "timing_begin")
+    cfm.sample(cond=cond, text=text, duration=duration, lens=lens, steps=nfe, cfg_strength=args.cfg, sway_sampling_coef=-1.0, seed=0,
+               return_trajectory=False, use_graph=False)
+    _lib.check(lib.f5_plan_timing_end(plan, C.byref(ms), C.byref(cnt), _lib.stream_ptr()), "timing_end")
+    flops_qkv = 2.0 * rows * (3 * inner) * D
+
+    def site(i):
+        a, n = C.c_float(0.0), C.c_int(0)
+        _lib.check(lib.f5_plan_timing_site(plan, i, C.byref(a), C.byref(n)), "timing_site")
+        return a.value, n.value
+    es = 2 if args.precision == "bf16" else 4
+    xs = es  # storage bytes of a residual-stream element: fp16 in the bf16 production mode (blocks 1..21 of 22; the first reads fp32), fp32 otherwise
+    work = {  # algorithmic work per launch: FLOP for the MFMA-bound kernels (SURVEY 8d), bytes for the HBM-bound ones
+        "qkv": ("mfma", flops_qkv), "attention": ("mfma", 4.0 * rows * N * inner), "attn_out": ("mfma", 2.0 * rows * D * inner),
+        "ff1": ("mfma", 2.0 * rows * ff * D), "ff2": ("mfma", 2.0 * rows * D * ff), "conv31": ("mfma", 2.0 * rows * D * 64 * 31),
+        # input projection W_x . x (K = 100 padded to 128): 0.2 FLOP per byte -- HBM-bound: reads the noisy mel rows (bf16, 128 wide) and the
+        # hoisted part of the embedding, writes the GEMM operand (bf16) and the residual stream
+        "input_proj": ("hbm", rows * (128 * es // 2 + D * (xs + es + xs))),
+        "ln1": ("hbm", rows * D * (xs + es + es)),              # read x + the FF branch, write the normalised rows
+        "ln2": ("hbm", rows * D * (xs + es + es + xs + es)),    # read x + both branches, write x and the normalised rows
+    }
+    kernels = []
+    for i, name in enumerate(_lib.SITES):
+        t_ms, n = site(i)
+        if n == 0 or t_ms <= 0:
+            continue
+        bound, w = work[name]
+        if bound == "mfma":
+            a = w / (t_ms * 1e-3) / 1e12
+            kernels.append({"kernel": name, "bound": "mfma", "work": round(w / 1e9, 2), "work_unit": "GFLOP", "ms": round(t_ms, 4),
+                            "launches": n, "achieved": round(a, 1), "unit": "TFLOP/s", "frac": round(a / MFMA_BF16_PEAK_TFLOPS, 4)})
+        else:
+            a = w / (t_ms * 1e-3) / 1e9
+            kernels.append({"kernel": name, "bound": "hbm", "work": round(w / 1e6, 1), "work_unit": "MB", "ms": round(t_ms, 4),
+                            "launches": n, "achieved": round(a, 1), "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4)})
+    return ms.value, cnt.value, flops_qkv, kernels
+
+
+def extra_workloads(args, dev, model, cfm):
+    """The other single-GPU configurations of BASELINE.json, measured after the C2 line so that the driver's default run records them too:
+    C4 (long form, 8 x 4096: 2 timed sample() calls + the in-situ kernel table) and C5 (Vocos.decode on the generated part of C2)."""
+    import torch
+    out = {}
+    B, N, nfe = WORKLOADS["C4"][0], WORKLOADS["C4"][1], args.nfe
+    batch = synth_batch(B, N, dev, seed=0)
+    cond, text, lens, duration = batch
+    kw = dict(cond=cond, text=text, duration=duration, lens=lens, steps=nfe, cfg_strength=args.cfg, sway_sampling_coef=-1.0, seed=0,
+              return_trajectory=False, use_graph=not args.no_graph)
+    cfm.sample(**kw)  # warm-up (captures the graph)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = 2
+    for _ in range(steps):
+        o, _ = cfm.sample(**kw)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    assert torch.isfinite(o).all()
+    _, _, _, kernels = insitu_kernels(model, cfm, batch, B, N, nfe, args)
+    attn = next((k for k in kernels if k["kernel"] == "attention"), None)
+    per_token = 378.9e6 + 90112.0 * N
+    flops = per_token * B * N * (2 if args.cfg >= 1e-5 else 1) * nfe * steps
+    out["C4"] = {"value": round(B * N * steps / el, 2), "unit": "mel-frames/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
+                 "rtf": round(el / (B * (N - N // 3) * 256 / 24000.0 * steps), 6),
+                 "config": f"C4 long form: {B} utterances x seq_len {N} (N_ref={N // 3}), NFE={nfe} CFG={args.cfg:g} sway=-1, bf16, hipGraph",
+                 "attention_frac": attn["frac"] if attn else None, "attention_ms": attn["ms"] if attn else None,
+                 "loop_mfma_frac": round(flops / el / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "kernels": kernels}
+    del batch, cond, text, lens, duration, o
+    torch.cuda.empty_cache()
+    v = bench_vocos(args, dev, T=683, B=32, steps=20, warmup=3)
+    out["C5"] = {"value": v["value"], "unit": v["unit"], "ms_per_step": v["ms_per_step"], "rtf": v["rtf"], "config": v["config"]["workload"],
+                 "head_gbs": v["roofline"]["achieved"], "head_frac": v["roofline"]["frac"],
+                 "backbone_tflops_f32": v["roofline"]["backbone_tflops_f32"], "cpu_baseline": v.get("cpu_baseline")}
+    return out
 
 
 def main():
@@ -222,6 +316,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="C2 run: skip the C4 / C5 measurements recorded under `workloads`")
     args = ap.parse_args()
 
     env_world = os.environ.get("WORLD_SIZE")
@@ -263,7 +358,8 @@ def main():
     if args.workload == "vocos":
         if world > 1:
             sys.exit("bench.py: --workload vocos is a single-GPU measurement")
-        return bench_vocos(args, dev)
+        print(json.dumps(bench_vocos(args, dev)), flush=True)
+        return
 
     wl_B, wl_N = WORKLOADS[args.workload]
     N, nfe = args.seq_len or wl_N, args.nfe
@@ -323,7 +419,7 @@ def main():
     result = {
         "metric": "mel-frames/s", "value": round(value, 2), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": args.scaling if world > 1 else "weak",
+        "scaling": args.scaling,  # "strong" (default): the same 32 utterances whatever the rank count; "weak": 32 per GPU
         "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "rtf": round(elapsed / gen_audio_s, 6),
         "config": {"workload": f"{args.workload if (N, B_req) == (wl_N, wl_B) else 'custom'} F5TTS_Base random-init, CFM.sample euler NFE={nfe} "
@@ -338,51 +434,14 @@ def main():
     if rank == 0:
         cfg_on = args.cfg >= 1e-5
         rows = (2 if cfg_on else 1) * B * N
-        inner, D, ff, depth = 16 * 64, 1024, 2048, BASE_ARCH["depth"]
-        # in situ: one extra eager sample() with a HIP event pair around every block kernel (6 per block + 3 per evaluation),
-        # on the stream the kernels run on; these are the same launches rocprofv3 averages in profiles/
-        plan = model.plan(B, N, nfe)
-        ms, cnt = C.c_float(0.0), C.c_int(0)
-        _lib.check(lib.f5_plan_timing_begin(plan, (7 * depth + 4) * nfe), "timing_begin")
-        cfm.sample(cond=cond, text=text, duration=duration, lens=lens, steps=nfe, cfg_strength=args.cfg, sway_sampling_coef=-1.0, seed=0,
-                   return_trajectory=False, use_graph=False)
-        _lib.check(lib.f5_plan_timing_end(plan, C.byref(ms), C.byref(cnt), _lib.stream_ptr()), "timing_end")
-        flops_qkv = 2.0 * rows * (3 * inner) * D
-        achieved = flops_qkv / (ms.value * 1e-3) / 1e12
-
-        def site(i):
-            a, n = C.c_float(0.0), C.c_int(0)
-            _lib.check(lib.f5_plan_timing_site(plan, i, C.byref(a), C.byref(n)), "timing_site")
-            return a.value, n.value
-        es = 2 if args.precision == "bf16" else 4
-        xs = es  # storage bytes of a residual-stream element: fp16 in the bf16 production mode (blocks 1..21 of 22; the first reads fp32), fp32 otherwise
-        work = {  # algorithmic work per launch: FLOP for the MFMA-bound kernels, bytes for the HBM-bound LayerNorm passes
-            "qkv": ("mfma", flops_qkv), "attention": ("mfma", 4.0 * rows * N * inner), "attn_out": ("mfma", 2.0 * rows * D * inner),
-            "ff1": ("mfma", 2.0 * rows * ff * D), "ff2": ("mfma", 2.0 * rows * D * ff), "conv31": ("mfma", 2.0 * rows * D * 64 * 31),
-            "input_proj": ("mfma", 2.0 * rows * D * 100),
-            "ln1": ("hbm", rows * D * (xs + es + es)),              # read x + the FF branch, write the normalised rows
-            "ln2": ("hbm", rows * D * (xs + es + es + xs + es)),    # read x + both branches, write x and the normalised rows
-        }
-        kernels = []
-        for i, name in enumerate(_lib.SITES):
-            t_ms, n = site(i)
-            if n == 0 or t_ms <= 0:
-                continue
-            bound, w = work[name]
-            if bound == "mfma":
-                a = w / (t_ms * 1e-3) / 1e12
-                kernels.append({"kernel": name, "bound": "mfma", "work": round(w / 1e9, 2), "work_unit": "GFLOP", "ms": round(t_ms, 4),
-                                "launches": n, "achieved": round(a, 1), "unit": "TFLOP/s", "frac": round(a / MFMA_BF16_PEAK_TFLOPS, 4)})
-            else:
-                a = w / (t_ms * 1e-3) / 1e9
-                kernels.append({"kernel": name, "bound": "hbm", "work": round(w / 1e6, 1), "work_unit": "MB", "ms": round(t_ms, 4),
-                                "launches": n, "achieved": round(a, 1), "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4)})
+        ms_qkv, n_qkv, flops_qkv, kernels = insitu_kernels(model, cfm, (cond, text, lens, duration), B, N, nfe, args)
+        achieved = flops_qkv / (ms_qkv * 1e-3) / 1e12
         traffic, traffic_src = recorded_traffic("qkv", rows, N)
         result["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
                               "traffic": traffic, "traffic_source": traffic_src,
                               "kernel": "gemm_fast_kernel<256,128,DENSE,QKV+RoPE epilogue,persistent grid>",
-                              "launch": f"M={rows} N=3072 K=1024, {flops_qkv / 1e9:.1f} GFLOP, {ms.value:.4f} ms mean over {cnt.value} launches inside an "
+                              "launch": f"M={rows} N=3072 K=1024, {flops_qkv / 1e9:.1f} GFLOP, {ms_qkv:.4f} ms mean over {n_qkv} launches inside an "
                                         f"eager sample() (HIP event pairs on the launch stream)",
                               "kernels": kernels}
         # what the matrix pipe itself sustains on THIS device (register-resident MFMA stream, no memory traffic): clock-limited with
@@ -400,6 +459,9 @@ def main():
         result["loop_mfma_frac"] = round(total_flops / elapsed / 1e12 / world / MFMA_BF16_PEAK_TFLOPS, 4)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only (the other ranks would sit in the barrier for its 15 s)
             result["cpu_baseline"] = cpu_baseline(model, N, nfe)
+        if world == 1 and args.workload == "C2" and not args.no_extra and (N, B_req) == (wl_N, wl_B) and args.precision == "bf16":
+            del cond, text, lens, duration
+            result["workloads"] = extra_workloads(args, dev, model, cfm)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

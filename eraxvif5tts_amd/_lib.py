@@ -59,6 +59,7 @@ _PROTOS = {
     "f5_plan_timing_site": (_I, [_P, _I, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "f5_plan_set_tap": (_I, [_P, C.c_char_p, _P]),
     "f5_plan_set_option": (_I, [_P, C.c_char_p, _I]),
+    "f5_plan_get_option": (_I, [_P, C.c_char_p, C.POINTER(C.c_int)]),
     "f5_duration_predict": (_I, [C.POINTER(DurationWeights), _I, _I, _P, _I, _P, _P, _P, _P]),
     "f5_op_linear": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
     "f5_op_linear_fused": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P]),

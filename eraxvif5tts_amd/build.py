@@ -19,7 +19,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libf5hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
-         "-Wno-unused-but-set-variable", "-ffp-contract=off"]
+         "-Wno-unused-but-set-variable", "-ffp-contract=off", "-fvisibility=hidden"]
 
 
 # per-file extra flags: the hand-laid vector stream of the attention kernel must not be re-packed into v_pk_*_f32 by the SLP vectorizer

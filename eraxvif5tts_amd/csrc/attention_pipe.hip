@@ -389,7 +389,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE,
                 load_m((t + 2) * KT);
             }
             F5_FENCE();
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MASKED ? 1 : 0) : "memory");  // (the mask byte of tile t+2 may stay in flight)
+            // Every LDS-DMA piece of this wave has landed.  vmcnt(0) in the MASKED build too: load_m above issues its byte load only for
+            // keys inside the sequence and only with a mask array, so "the youngest operation is the mask byte" (vmcnt(1)) does not hold
+            // for a ragged single utterance (mask == nullptr, N % 64 != 0) -- the last piece of V(t+1) would be left uncovered.  Free: the
+            // compiler waits for the byte right behind its load anyway (it feeds the ballot of the next tail).
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             F5_FENCE();
         }

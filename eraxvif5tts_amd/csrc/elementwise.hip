@@ -35,10 +35,19 @@ template <typename XT> __device__ __forceinline__ void store_res4(XT* p, const f
     }
 }
 
+// Range guard of the fp16 residual stream (the stores above SATURATE at +-65504): a lane that read, formed or stored an element at or beyond
+// fp16's largest finite value -- or a NaN, which the running sum carries -- raises the plan's flag word; f5_sample reads it after the loop
+// and repeats the call with fp32 residual storage (model.hip).  One compare per row on the common path.
+__device__ __forceinline__ void res_range_guard(unsigned* sat, float amax, float partial_sum) {
+    const bool bad = !(amax < 65504.0f) || !(partial_sum == partial_sum);
+    if (sat && __builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) __hip_atomic_store(sat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <typename TO, int MAXV, int YMODE, bool FULL, typename XI = float, typename XO = float>
 __global__ __launch_bounds__(256) void layernorm_kernel(const XI* x, XO* xo /* may be x itself */, int ldx, int rows, int dim, const TO* __restrict__ y,
                                                         int ldy, const TO* __restrict__ y2, const float* __restrict__ mul, const float* __restrict__ add,
-                                                        int mod_bstride, int rows_per_batch, float add_one, TO* __restrict__ out, int ldo) {
+                                                        int mod_bstride, int rows_per_batch, float add_one, TO* __restrict__ out, int ldo,
+                                                        unsigned* sat) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -74,18 +83,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const XI* x, XO* xo /* m
         }
     }
     float s = 0.f;
+    [[maybe_unused]] float amax = 0.f;  // fp16 residual storage: largest |element| read or formed in this row (range guard below)
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + i * 64;
         if (FULL || c < nvec) {
+            if constexpr (sizeof(XI) == 2) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[i][0]), fabsf(v[i][1])), fmaxf(fabsf(v[i][2]), fabsf(v[i][3]))));
             if constexpr (YMODE != 0) {
                 v[i] += widen(yr[i]);
                 if constexpr (YMODE == 3) v[i] += widen(yr2[i]);
                 if constexpr (YMODE != 2) store_res4<XO>(xw + c * 4, v[i]);
             }
+            if constexpr (sizeof(XI) == 2 || sizeof(XO) == 2) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[i][0]), fabsf(v[i][1])), fmaxf(fabsf(v[i][2]), fabsf(v[i][3]))));
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
     }
+    if constexpr (sizeof(XI) == 2 || sizeof(XO) == 2) res_range_guard(sat, amax, s);
     const float mean = wave_sum(s) / (float)dim;
     float q = 0.f;
 #pragma unroll
@@ -124,7 +137,7 @@ template <int YMODE>
 __global__ __launch_bounds__(256) void layernorm1024_h_kernel(const _Float16* x, _Float16* xo, int ldx, int rows, const bf16_t* __restrict__ y, int ldy,
                                                               const bf16_t* __restrict__ y2, const float* __restrict__ mul, const float* __restrict__ add,
                                                               int mod_bstride, int rows_per_batch, float add_one, bf16_t* __restrict__ out, int ldo,
-                                                              PrefetchSet pf) {
+                                                              PrefetchSet pf, unsigned* sat) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     // weight prefetch: one dword per 128-byte line is enough to pull the line in; lane l of the wave of row w touches line 64 w + l of every
@@ -158,15 +171,19 @@ __global__ __launch_bounds__(256) void layernorm1024_h_kernel(const _Float16* x,
             a4[i][hh] = *reinterpret_cast<const f32x4*>(add + moff + c + 4 * hh);
         }
     }
-    float s = 0.f;
+    float s = 0.f, amax = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float t = (float)xr[i][e];
-            if constexpr (YMODE != 0) t += (float)yr[i][e];
+            if constexpr (YMODE != 0) {
+                amax = fmaxf(amax, fabsf(t));  // an element an earlier pass already clamped
+                t += (float)yr[i][e];
+            }
             if constexpr (YMODE == 3) t += (float)yr2[i][e];
             v[i][e] = t;
+            amax = fmaxf(amax, fabsf(t));
         }
         if constexpr (YMODE == 1 || YMODE == 3) {
             f16x8 w;
@@ -178,6 +195,7 @@ __global__ __launch_bounds__(256) void layernorm1024_h_kernel(const _Float16* x,
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         s += (v[i][4] + v[i][5]) + (v[i][6] + v[i][7]);
     }
+    res_range_guard(sat, amax, s);
     const float mean = wave_sum(s) / 1024.0f;
     float q = 0.f;
 #pragma unroll
@@ -202,16 +220,16 @@ int g_ln_wide = 1;  // tuning knob ("ln_wide"): 16-byte form of the LayerNorm pa
 
 template <typename TO, int MAXV, typename XI = float, typename XO = float>
 static void ln_launch(const void* x, void* xo, int ldx, int rows, int dim, const void* y, int ldy, const void* y2, int ymode, const float* mul,
-                      const float* add, int mod_bstride, int rows_per_batch, float one, void* out, int ldo, hipStream_t stream) {
+                      const float* add, int mod_bstride, int rows_per_batch, float one, void* out, int ldo, hipStream_t stream, unsigned* sat) {
     dim3 grid(cdiv(rows, 4)), block(256);
 #define F5_LN_CASE(M)                                                                                                                        \
     do {                                                                                                                                     \
         if (dim == MAXV * 256)                                                                                                               \
             hipLaunchKernelGGL((layernorm_kernel<TO, MAXV, M, true, XI, XO>), grid, block, 0, stream, (const XI*)x, (XO*)xo, ldx, rows, dim, \
-                               (const TO*)y, ldy, (const TO*)y2, mul, add, mod_bstride, rows_per_batch, one, (TO*)out, ldo);                 \
+                               (const TO*)y, ldy, (const TO*)y2, mul, add, mod_bstride, rows_per_batch, one, (TO*)out, ldo, sat);            \
         else                                                                                                                                 \
             hipLaunchKernelGGL((layernorm_kernel<TO, MAXV, M, false, XI, XO>), grid, block, 0, stream, (const XI*)x, (XO*)xo, ldx, rows, dim, \
-                               (const TO*)y, ldy, (const TO*)y2, mul, add, mod_bstride, rows_per_batch, one, (TO*)out, ldo);                 \
+                               (const TO*)y, ldy, (const TO*)y2, mul, add, mod_bstride, rows_per_batch, one, (TO*)out, ldo, sat);            \
     } while (0)
     if (ymode == 0) F5_LN_CASE(0);
     else if (ymode == 1) F5_LN_CASE(1);
@@ -225,7 +243,7 @@ static void ln_launch(const void* x, void* xo, int ldx, int rows, int dim, const
 // the same buffer as xin or another one of the same leading dimension).  fp16 residual storage exists for the bf16 output type only.
 int launch_layernorm_res(int precision_out, const void* xin, int xin_f16, void* xout, int xout_f16, int ldx, int rows, int dim, const void* y, int ldy,
                          const void* y2, int ymode, const float* mul, const float* add, int mod_bstride, int rows_per_batch, int add_one, void* out,
-                         int ldo, hipStream_t stream, const PrefetchSet* prefetch) {
+                         int ldo, hipStream_t stream, const PrefetchSet* prefetch, unsigned* sat) {
     if (rows <= 0) return 0;
     if (dim % 4 != 0 || dim > 2048 || (ldx & 3) || (ldo & 3) || (mod_bstride & 3) || (y && (ldy & 3)))
         return f5_fail(F5_EINVAL, "layernorm: dim=%d unsupported", dim);
@@ -238,9 +256,9 @@ int launch_layernorm_res(int precision_out, const void* xin, int xin_f16, void* 
 #define F5_LN_DIM(TO, XI, XO)                                                                                                                  \
     do {                                                                                                                                       \
         if (dim <= 1024)                                                                                                                       \
-            ln_launch<TO, 4, XI, XO>(xin, xout, ldx, rows, dim, y, ldy, y2, ymode, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream); \
+            ln_launch<TO, 4, XI, XO>(xin, xout, ldx, rows, dim, y, ldy, y2, ymode, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream, sat); \
         else                                                                                                                                   \
-            ln_launch<TO, 8, XI, XO>(xin, xout, ldx, rows, dim, y, ldy, y2, ymode, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream); \
+            ln_launch<TO, 8, XI, XO>(xin, xout, ldx, rows, dim, y, ldy, y2, ymode, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream, sat); \
     } while (0)
     if (precision_out == F5_PREC_BF16 && xin_f16 && xout_f16 && dim == 1024 && g_ln_wide && !(ldx & 7) && !(ldo & 7) && !(y && (ldy & 7))) {
         dim3 grid(cdiv(rows, 4)), block(256);
@@ -248,7 +266,7 @@ int launch_layernorm_res(int precision_out, const void* xin, int xin_f16, void* 
         if (prefetch) pfs = *prefetch;
 #define F5_LN_W(M)                                                                                                                              \
     hipLaunchKernelGGL((layernorm1024_h_kernel<M>), grid, block, 0, stream, (const _Float16*)xin, (_Float16*)xout, ldx, rows, (const bf16_t*)y, ldy, \
-                       (const bf16_t*)y2, mul, add, mod_bstride, rows_per_batch, one, (bf16_t*)out, ldo, pfs)
+                       (const bf16_t*)y2, mul, add, mod_bstride, rows_per_batch, one, (bf16_t*)out, ldo, pfs, sat)
         if (ymode == 0) F5_LN_W(0);
         else if (ymode == 1) F5_LN_W(1);
         else if (ymode == 2) F5_LN_W(2);
@@ -273,15 +291,22 @@ int launch_layernorm_res(int precision_out, const void* xin, int xin_f16, void* 
 }
 
 // fp32 -> fp16 (saturating) copy of n elements (n % 4 == 0): the hoisted part of the input embedding, once per sample() and branch
-__global__ __launch_bounds__(256) void f32_to_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, size_t nvec) {
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) store_res4<_Float16>(dst + i * 4, load_res4<float>(src + i * 4));
+__global__ __launch_bounds__(256) void f32_to_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, size_t nvec, unsigned* sat) {
+    float amax = 0.f, sum = 0.f;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        const f32x4 v = load_res4<float>(src + i * 4);
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        sum += (v[0] + v[1]) + (v[2] + v[3]);
+        store_res4<_Float16>(dst + i * 4, v);
+    }
+    res_range_guard(sat, amax, sum);
 }
-int launch_f32_to_f16(const float* src, void* dst, size_t n, hipStream_t stream) {
+int launch_f32_to_f16(const float* src, void* dst, size_t n, hipStream_t stream, unsigned* sat) {
     if (n == 0) return 0;
     if (n & 3) return f5_fail(F5_EINVAL, "f32_to_f16: n %% 4 != 0");
     const size_t nvec = n >> 2;
     const int grid = (int)(nvec / 256 + 1 < 4096 ? nvec / 256 + 1 : 4096);
-    hipLaunchKernelGGL(f32_to_f16_kernel, dim3(grid), dim3(256), 0, stream, src, (_Float16*)dst, nvec);
+    hipLaunchKernelGGL(f32_to_f16_kernel, dim3(grid), dim3(256), 0, stream, src, (_Float16*)dst, nvec, sat);
     F5_LAUNCH_CHECK();
     return 0;
 }
@@ -290,7 +315,7 @@ int launch_layernorm_add2(int precision_out, float* x, int ldx, int rows, int di
                           const float* mul, const float* add, int mod_bstride, int rows_per_batch, int add_one, void* out, int ldo,
                           hipStream_t stream) {
     return launch_layernorm_res(precision_out, x, 0, x, 0, ldx, rows, dim, y, ldy, y2, ymode, mul, add, mod_bstride, rows_per_batch, add_one, out, ldo,
-                                stream);
+                                stream, nullptr, nullptr);
 }
 
 int launch_layernorm_add(int precision_out, float* x, int ldx, int rows, int dim, const void* y, int ldy, const float* mul, const float* add,

@@ -27,7 +27,7 @@ __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];  // zer
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 
 template <int BN, int WM, int MODE, int EPI, int VAR, int NS>
-__global__ __launch_bounds__(512, (BN == 64 ? 4 : 2)) void gemm_fast_kernel(GemmParams p, int tiles_n, int nblocks) {
+__global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int tiles_n, int nblocks) {
     constexpr int BM = 256, BK = 32, WN = 64, NSTAGE = NS;
     constexpr int WAVES_N = BN / WN;
     constexpr int MI = WM / 16, NI = WN / 16;

@@ -76,6 +76,14 @@ struct f5_plan_s {
     int32_t *text_in = nullptr, *lens_in = nullptr, *dur_in = nullptr;
     int rope_n = 0;
     int gemm_kernel = -1, attn_kernel = -1;  // -1 = auto (tuned kernel when it supports the problem)
+    // Range guard of the fp16 residual stream (bf16 production mode): the LayerNorm passes raise `sat_flag` (device word) when an element of
+    // the stream reaches fp16's largest finite value or is NaN; f5_sample reads it after the loop (the call's one synchronisation) and
+    // repeats the loop with fp32 residual storage, which this plan then keeps (`res_f16` = 0).
+    unsigned* sat_flag = nullptr;
+    unsigned* sat_host = nullptr;  // pinned
+    int res_f16 = -1;              // plan option "residual_f16": -1 = the process-wide knob, 0 = fp32 storage, 1 = fp16 storage
+    int sat_check = 1;             // plan option "residual_guard": 0 = never read the flag (f5_sample stays fully asynchronous)
+    int fallbacks = 0;             // calls repeated with fp32 storage so far (f5_plan_get_option "residual_fallbacks")
     std::map<std::string, float*> taps;
     std::vector<float> mod_tv;  // evaluation times the AdaLN rows in `mod` were computed for (empty = stale); see f5_sample
     hipStream_t mod_stream = nullptr;  // ... and the stream they were computed on (a call on another stream recomputes them)
@@ -86,6 +94,7 @@ struct f5_plan_s {
     std::vector<hipEvent_t> ev;
     std::vector<int> ev_site;  // call site of pair i (F5_SITE_*)
     size_t ev_used = 0;
+    bool ev_overflow = false;  // a launch found the event pool full: the means would cover the early launches only
     double site_ms[F5_SITE_COUNT] = {0};
     int site_n[F5_SITE_COUNT] = {0};
 };
@@ -100,6 +109,7 @@ template <typename F> static int timed(f5_plan_s* p, int site, hipStream_t st, F
         p->ev_used += 2;
         return rc;
     }
+    if (p->timing) p->ev_overflow = true;
     return launch();
 }
 
@@ -433,8 +443,15 @@ extern "C" int f5_plan_create(f5_model_t m, int max_batch, int max_seq, int max_
             }
         if ((rc = f5_upload_f32(A, rope.data(), rope.size(), &p->rope))) break;
         p->rope_n = max_seq;
+        if ((rc = A.alloc_t(&p->sat_flag, 4))) break;
+        if (hipHostMalloc((void**)&p->sat_host, 16, hipHostMallocDefault) != hipSuccess) {
+            rc = f5_fail(F5_ENOMEM, "hipHostMalloc failed");
+            break;
+        }
+        *p->sat_host = 0u;
     } while (0);
     if (rc) {
+        if (p->sat_host) (void)hipHostFree(p->sat_host);
         delete p;
         return rc;
     }
@@ -452,6 +469,7 @@ extern "C" int f5_plan_destroy(f5_plan_t p) {
     }
     if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+    if (p->sat_host) (void)hipHostFree(p->sat_host);
     delete p;
     return 0;
 }
@@ -463,6 +481,10 @@ extern "C" int f5_plan_set_option(f5_plan_t p, const char* key, int value) {
         p->gemm_kernel = value;
     else if (strcmp(key, "attn_kernel") == 0)
         p->attn_kernel = value;
+    else if (strcmp(key, "residual_f16") == 0)
+        p->res_f16 = value < 0 ? -1 : (value != 0);
+    else if (strcmp(key, "residual_guard") == 0)
+        p->sat_check = value != 0;
     else
         return f5_fail(F5_EINVAL, "unknown option '%s'", key);
     for (auto& g : p->graphs) {  // captured graphs baked the previous choice
@@ -473,6 +495,25 @@ extern "C" int f5_plan_set_option(f5_plan_t p, const char* key, int value) {
     return 0;
 }
 
+static bool plan_res_f16(const f5_plan_s* p);
+
+extern "C" int f5_plan_get_option(f5_plan_t p, const char* key, int* value) {
+    if (!p || !key || !value) return f5_fail(F5_EINVAL, "null argument");
+    if (strcmp(key, "gemm_kernel") == 0)
+        *value = p->gemm_kernel;
+    else if (strcmp(key, "attn_kernel") == 0)
+        *value = p->attn_kernel;
+    else if (strcmp(key, "residual_f16") == 0)
+        *value = plan_res_f16(p) ? 1 : 0;  // what the next evaluation will use
+    else if (strcmp(key, "residual_guard") == 0)
+        *value = p->sat_check;
+    else if (strcmp(key, "residual_fallbacks") == 0)
+        *value = p->fallbacks;
+    else
+        return f5_fail(F5_EINVAL, "unknown option '%s'", key);
+    return 0;
+}
+
 extern "C" int f5_plan_timing_begin(f5_plan_t p, int max_launches) {
     if (!p || max_launches <= 0) return f5_fail(F5_EINVAL, "bad argument");
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
@@ -480,6 +521,7 @@ extern "C" int f5_plan_timing_begin(f5_plan_t p, int max_launches) {
     p->ev_site.assign((size_t)max_launches, 0);
     for (auto& e : p->ev) F5_HIP(hipEventCreate(&e));
     p->ev_used = 0;
+    p->ev_overflow = false;
     p->timing = true;
     return 0;
 }
@@ -504,6 +546,10 @@ extern "C" int f5_plan_timing_end(f5_plan_t p, float* avg_ms, int* launches, f5_
     p->ev_used = 0;
     *avg_ms = p->site_n[F5_SITE_QKV] ? (float)(p->site_ms[F5_SITE_QKV] / p->site_n[F5_SITE_QKV]) : 0.f;
     *launches = p->site_n[F5_SITE_QKV];
+    if (p->ev_overflow) {
+        p->ev_overflow = false;
+        return f5_fail(F5_ESTATE, "f5_plan_timing_begin's max_launches was too small: launches beyond it were not timed (7 per block + 3 per evaluation)");
+    }
     return 0;
 }
 
@@ -529,6 +575,12 @@ int g_w_prefetch = 16384;  // tuning knob ("w_prefetch"): LayerNorm passes prefe
                             // (0 = never).  M = 8192: +2.3 %, M = 2048: +2.9 % mel-frames/s; M = 65536: no effect (each weight line serves 256 token tiles there)
 int g_res_f16 = 1;   // tuning knob ("residual_f16"): bf16 production mode keeps the residual stream in fp16 from the first block on (0 = fp32)
 int g_ln_defer = 1;  // tuning knob ("ln_defer"): write the residual stream once per DiT block (0 = after every LayerNorm pass)
+
+// fp16 residual storage for this plan's evaluations (bf16 mode without stage taps; the plan option overrides the process-wide knob)
+static bool plan_res_f16(const f5_plan_s* p) {
+    const bool want = p->res_f16 < 0 ? g_res_f16 != 0 : p->res_f16 != 0;
+    return want && p->taps.empty() && g_ln_defer && p->m->cfg.precision == F5_PREC_BF16 && p->xres16 && p->base16;
+}
 
 static GemmParams gp_zero() {
     GemmParams g;
@@ -610,7 +662,7 @@ static int compute_base(f5_plan_s* p, const float* cond, const int32_t* lens, co
     g.A = ab; g.lda = kct; g.W = m->w_ct; g.ldw = kct; g.M = nb * N; g.N = D; g.K = kct;
     g.bias = m->b_in; g.out_f = p->base + row0 * D; g.ldof = D;
     F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_STORE_F32, st));
-    if (p->base16) F5_TRY(launch_f32_to_f16(p->base + row0 * D, (char*)p->base16 + row0 * D * 2, (size_t)nb * N * D, st));
+    if (p->base16) F5_TRY(launch_f32_to_f16(p->base + row0 * D, (char*)p->base16 + row0 * D * 2, (size_t)nb * N * D, st, plan_res_f16(p) ? p->sat_flag : nullptr));
     return 0;
 }
 
@@ -632,7 +684,8 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
     // fp16 (utils_infer.py:184-193); arithmetic stays fp32 and the branches stay bf16.  Bytes per block of the two LayerNorm passes:
     // 1 408 -> 1 024 MiB at C2; of the input embedding 656 -> 400 MiB.
     const bool defer = p->taps.empty() && g_ln_defer;
-    const bool r16 = defer && P == F5_PREC_BF16 && g_res_f16 && p->xres16 && p->base16;
+    const bool r16 = plan_res_f16(p);
+    unsigned* const sat = r16 ? p->sat_flag : nullptr;
     if (r16) {
         g.addend = reinterpret_cast<const float*>(p->base16);
         g.out_f = reinterpret_cast<float*>(p->xres16);
@@ -669,7 +722,7 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
                         {(unsigned)(D * ff * wes), (unsigned)(3 * inner * D * wes), 0u, 0u}};
         F5_TRY(timed(p, F5_SITE_LN1, st, [&] {
             return launch_layernorm_res(P, xin, in16, xout, r16, D, rows, D, p->yT, D, nullptr, defer ? 2 : 1, ml + D, ml, mod_bstride, N, 1, p->hT, D, st,
-                                        wpf ? &pf1 : nullptr);
+                                        wpf ? &pf1 : nullptr, sat);
         }));
         if (l == 0) F5_TRY(tap_f32(p, "input_embed", p->xres, D, rows, D, st));
         if (l > 0) F5_TRY(tap_f32(p, "blk" + std::to_string(l - 1) + ".out", p->xres, D, rows, D, st));
@@ -721,7 +774,7 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         // x += y; n2 = LN(x) * (1 + scale_mlp) + shift_mlp
         F5_TRY(timed(p, F5_SITE_LN2, st, [&] {
             return launch_layernorm_res(P, xin, in16, xout, r16, D, rows, D, p->yT, D, defer ? p->yA : nullptr, defer ? 3 : 1, ml + 4 * D, ml + 3 * D,
-                                        mod_bstride, N, 1, p->hT, D, st, wpf ? &pf2 : nullptr);
+                                        mod_bstride, N, 1, p->hT, D, st, wpf ? &pf2 : nullptr, sat);
         }));
         g = gp_zero();
         g.A = p->hT; g.lda = D; g.W = b.w_ff1; g.ldw = D; g.M = rows; g.N = ff; g.K = D;
@@ -736,7 +789,7 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
     const float* mf = modp + (size_t)c.depth * 6 * D;  // final AdaLN: (scale, shift) (modules.py:333)
     // (no stage tap: the stream itself is not needed any more, so the last add is not written back)
     F5_TRY(launch_layernorm_res(P, r16 ? p->xres16 : (const void*)p->xres, r16, r16 ? p->xres16 : (void*)p->xres, r16, D, rows, D, p->yT, D, nullptr,
-                                defer ? 2 : 1, mf, mf + D, mod_bstride, N, 1, p->hT, D, st));
+                                defer ? 2 : 1, mf, mf + D, mod_bstride, N, 1, p->hT, D, st, nullptr, sat));
     F5_TRY(tap_f32(p, "blk" + std::to_string(c.depth - 1) + ".out", p->xres, D, rows, D, st));
     F5_TRY(tap_t(p, "final_norm", p->hT, D, rows, D, st));
     g = gp_zero();
@@ -785,6 +838,7 @@ static int sample_body(f5_plan_s* p, const SampleArgs& a, hipStream_t st) {
     const int B = a.B, N = a.N, mel = c.mel_dim, bn = B * N;
     const int nev = a.method == F5_ODE_MIDPOINT ? 2 * a.steps : a.steps;
     const size_t state = (size_t)bn * mel;
+    F5_HIP(hipMemsetAsync(p->sat_flag, 0, 4, st));  // range guard of the fp16 residual stream: a node of the graph, so every replay starts clean
     // (the AdaLN modulation rows of all evaluation times are already in p->mod: f5_sample keeps them across calls)
     // text embeddings are constants of the whole sample() (the reference caches them per branch, dit.py:202-210)
     F5_TRY(compute_text_embed(p, p->text_in, a.nt, B, N, 0, p->te[0], st));
@@ -868,48 +922,73 @@ extern "C" int f5_sample(f5_plan_t p, int B, int N, const float* cond, const int
     if (durations) F5_HIP(hipMemcpyAsync(p->dur_in, durations, B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
 
     SampleArgs a{B, N, nt_eff, steps, ode_method, cfg_strength >= 1e-5f ? 1 : 0, durations ? 1 : 0, cfg_strength};  // cfm.py:167
-    if (use_graph && p->taps.empty() && !p->timing) {
-        GraphEntry* ge = nullptr;
-        for (size_t i = 0; i < p->graphs.size();) {  // a tuning knob changed since the capture: the graph baked the old kernel choice
-            if (p->graphs[i].epoch != g_tuning_epoch) {
-                (void)hipGraphExecDestroy(p->graphs[i].exec);
-                (void)hipGraphDestroy(p->graphs[i].graph);
-                p->graphs.erase(p->graphs.begin() + i);
-            } else {
-                ++i;
-            }
+    auto drop_graphs = [&]() {
+        for (auto& g : p->graphs) {
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            if (g.graph) (void)hipGraphDestroy(g.graph);
         }
-        for (auto& g : p->graphs)
-            if (g.B == B && g.N == N && g.nt == a.nt && g.steps == steps && g.method == ode_method && g.cfg_on == a.cfg_on &&
-                g.mask_on == a.mask_on && g.cfg == a.cfg)
-                ge = &g;
-        if (!ge) {
-            GraphEntry g{B, N, a.nt, steps, ode_method, a.cfg_on, a.mask_on, a.cfg, g_tuning_epoch};
-            if (!p->cap_stream) F5_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
-            F5_HIP(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeRelaxed));
-            int rc = sample_body(p, a, p->cap_stream);
-            hipError_t e = hipStreamEndCapture(p->cap_stream, &g.graph);
-            if (rc != 0) {
-                if (g.graph) (void)hipGraphDestroy(g.graph);
-                return rc;
+        p->graphs.clear();
+    };
+    auto run_loop = [&]() -> int {
+        if (use_graph && p->taps.empty() && !p->timing) {
+            GraphEntry* ge = nullptr;
+            for (size_t i = 0; i < p->graphs.size();) {  // a tuning knob changed since the capture: the graph baked the old kernel choice
+                if (p->graphs[i].epoch != g_tuning_epoch) {
+                    (void)hipGraphExecDestroy(p->graphs[i].exec);
+                    (void)hipGraphDestroy(p->graphs[i].graph);
+                    p->graphs.erase(p->graphs.begin() + i);
+                } else {
+                    ++i;
+                }
             }
-            if (e != hipSuccess) return f5_fail(F5_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
-            e = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
-            if (e != hipSuccess) {
-                (void)hipGraphDestroy(g.graph);
-                return f5_fail(F5_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+            for (auto& g : p->graphs)
+                if (g.B == B && g.N == N && g.nt == a.nt && g.steps == steps && g.method == ode_method && g.cfg_on == a.cfg_on &&
+                    g.mask_on == a.mask_on && g.cfg == a.cfg)
+                    ge = &g;
+            if (!ge) {
+                GraphEntry g{B, N, a.nt, steps, ode_method, a.cfg_on, a.mask_on, a.cfg, g_tuning_epoch};
+                if (!p->cap_stream) F5_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
+                F5_HIP(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeRelaxed));
+                int rc = sample_body(p, a, p->cap_stream);
+                hipError_t e = hipStreamEndCapture(p->cap_stream, &g.graph);
+                if (rc != 0) {
+                    if (g.graph) (void)hipGraphDestroy(g.graph);
+                    return rc;
+                }
+                if (e != hipSuccess) return f5_fail(F5_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+                e = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
+                if (e != hipSuccess) {
+                    (void)hipGraphDestroy(g.graph);
+                    return f5_fail(F5_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+                }
+                if (p->graphs.size() >= 8) {  // small LRU-less cache: drop the oldest bucket
+                    (void)hipGraphExecDestroy(p->graphs[0].exec);
+                    (void)hipGraphDestroy(p->graphs[0].graph);
+                    p->graphs.erase(p->graphs.begin());
+                }
+                p->graphs.push_back(g);
+                ge = &p->graphs.back();
             }
-            if (p->graphs.size() >= 8) {  // small LRU-less cache: drop the oldest bucket
-                (void)hipGraphExecDestroy(p->graphs[0].exec);
-                (void)hipGraphDestroy(p->graphs[0].graph);
-                p->graphs.erase(p->graphs.begin());
-            }
-            p->graphs.push_back(g);
-            ge = &p->graphs.back();
+            F5_HIP(hipGraphLaunch(ge->exec, st));
+        } else {
+            F5_TRY(sample_body(p, a, st));
         }
-        F5_HIP(hipGraphLaunch(ge->exec, st));
-    } else {
-        F5_TRY(sample_body(p, a, st));
+        return 0;
+    };
+    const bool guarded = plan_res_f16(p) && p->sat_check && !p->timing;
+    F5_TRY(run_loop());
+    if (guarded) {
+        // The stream was stored as saturating fp16: one 4-byte read of the flag the LayerNorm passes raise (the call's only synchronisation;
+        // plan option "residual_guard" = 0 removes it).  A large-activation checkpoint must not clip silently: the loop is repeated with
+        // fp32 residual storage -- y0 is still traj[0], every other input is staged -- and the plan keeps fp32 storage from now on.
+        F5_HIP(hipMemcpyAsync(p->sat_host, p->sat_flag, 4, hipMemcpyDeviceToHost, st));
+        F5_HIP(hipStreamSynchronize(st));
+        if (*p->sat_host != 0u) {
+            p->res_f16 = 0;
+            ++p->fallbacks;
+            drop_graphs();  // they baked the fp16 kernels
+            F5_TRY(run_loop());
+        }
     }
     F5_TRY(launch_final_where(p->cond_in, p->traj + (size_t)steps * state, p->lens_in, B, N, mel, out, st));
     if (trajectory) F5_HIP(hipMemcpyAsync(trajectory, p->traj, (size_t)(steps + 1) * state * sizeof(float), hipMemcpyDeviceToDevice, st));

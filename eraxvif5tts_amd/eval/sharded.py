@@ -4,12 +4,12 @@ Model: the reference's only multi-GPU inference path, ``f5_tts/eval/eval_infer_b
 pre-bucketed prompt batches is split contiguously over the processes (``accelerator.split_between_processes``), every rank
 runs ``CFM.sample`` on its own batches with a full weight replica, and the only synchronisation is a barrier before and
 after.  There is no collective inside the ODE loop.  New here (asked for by the north star): the finished mels are
-gathered to every rank with ONE all_gather per call (``torch.distributed``; backend ``nccl`` is RCCL on ROCm, ``gloo`` on
+gathered to every rank with ONE data all_gather per call (the ragged metadata is derived locally from the batch list) (``torch.distributed``; backend ``nccl`` is RCCL on ROCm, ``gloo`` on
 CPU for the tests) instead of being written to per-rank files.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Sequence
+from typing import Callable, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -24,39 +24,48 @@ def split_between_processes(items: Sequence, rank: int, world_size: int):
     return items[start:end]
 
 
-def gather_utterances(local: List[torch.Tensor], frame_counts: List[int], mel_dim: int, device) -> List[torch.Tensor]:
-    """all_gather of a ragged list of [n_i, mel] tensors: one collective for the lengths, one for the padded payload.
+def gather_utterances(local: List[torch.Tensor], frame_counts: List[int], mel_dim: int, device,
+                      all_frame_counts: Optional[List[List[int]]] = None, force_collective: bool = False) -> List[torch.Tensor]:
+    """all_gather of a ragged list of [n_i, mel] tensors.  ONE data collective (the padded payload); the metadata -- how many utterances
+    each rank holds and how many frames each has -- is either handed in (``all_frame_counts[r]`` = frame counts of rank r: sample_sharded
+    derives it from the batch list every rank already has, no collective) or exchanged with ONE ``all_gather_object``.
     Returns the utterances of every rank in global (rank-major = original) order, on every rank."""
     world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):  # (force_collective: rehearse the RCCL calls on a one-GPU box)
         return list(local)
-    counts = torch.tensor([len(local)], device=device, dtype=torch.long)
-    all_counts = [torch.zeros_like(counts) for _ in range(world)]
-    dist.all_gather(all_counts, counts)
-    max_items = int(max(int(c) for c in all_counts))
-    lens = torch.zeros(max_items, device=device, dtype=torch.long)
-    if local:
-        lens[: len(local)] = torch.tensor(frame_counts, device=device, dtype=torch.long)
-    all_lens = [torch.zeros_like(lens) for _ in range(world)]
-    dist.all_gather(all_lens, lens)
-    max_frames = int(max(int(l.max()) for l in all_lens)) if max_items else 0
+    if all_frame_counts is None:
+        all_frame_counts = [None] * world
+        dist.all_gather_object(all_frame_counts, [int(c) for c in frame_counts])
+    rank = dist.get_rank()
+    assert [int(c) for c in all_frame_counts[rank]] == [int(c) for c in frame_counts], "frame counts of this rank disagree with the metadata"
+    max_items = max(len(c) for c in all_frame_counts)
+    max_frames = max((max(c) for c in all_frame_counts if len(c)), default=0)
     payload = torch.zeros(max_items, max_frames, mel_dim, device=device, dtype=torch.float32)
     for i, t in enumerate(local):
         payload[i, : t.shape[0]] = t
     gathered = [torch.zeros_like(payload) for _ in range(world)]
-    dist.all_gather(gathered, payload)  # the single data collective of the whole path
+    dist.all_gather(gathered, payload)  # the single data collective of the whole path (RCCL over xGMI under backend "nccl")
     out = []
     for r in range(world):
-        for i in range(int(all_counts[r])):
-            out.append(gathered[r][i, : int(all_lens[r][i])])
+        for i, n in enumerate(all_frame_counts[r]):
+            out.append(gathered[r][i, : int(n)])
     return out
 
 
+def _generated_frames(kw) -> List[int]:
+    """frames sample() returns for each utterance of one batch: out[i, lens_i:duration_i] (eval_infer_batch.py:185)."""
+    lens, dur = kw["lens"], kw["duration"]
+    return [int(dur[i]) - int(lens[i]) for i in range(len(lens))]
+
+
 @torch.no_grad()
-def sample_sharded(sample_fn: Callable, batches: Sequence[dict], mel_dim: int = 100, device="cuda", gather: bool = True):
+def sample_sharded(sample_fn: Callable, batches: Sequence[dict], mel_dim: int = 100, device="cuda", gather: bool = True,
+                   force_collective: bool = False):
     """batches: list of dicts with the keyword arguments of ``CFM.sample`` for one padded batch (cond [b, nc, mel], text,
     duration [b], lens [b], steps, ...).  Each rank runs its contiguous share; returns the generated part
-    ``out[i, lens_i:duration_i]`` of every utterance of every batch, in the original order (on every rank if gather)."""
+    ``out[i, lens_i:duration_i]`` of every utterance of every batch, in the original order (on every rank if gather).
+    Every rank holds the whole batch list (as every rank of the reference builds the whole prompt list before splitting it,
+    eval_infer_batch.py:160-163), so the gather's metadata needs no collective: one all_gather of the payload is the only exchange."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     mine = split_between_processes(list(batches), rank, world)
@@ -70,4 +79,5 @@ def sample_sharded(sample_fn: Callable, batches: Sequence[dict], mel_dim: int = 
             counts.append(gen.shape[0])
     if not gather:
         return local
-    return gather_utterances(local, counts, mel_dim, device)
+    all_counts = [[n for kw in split_between_processes(list(batches), r, world) for n in _generated_frames(kw)] for r in range(world)]
+    return gather_utterances(local, counts, mel_dim, device, all_frame_counts=all_counts, force_collective=force_collective)

@@ -6,6 +6,11 @@ Same constructor kwargs/defaults (:34-52), ``preprocess_reference(ref_audio_path
 use_duration_predictor, return_numpy, return_spectrogram)`` (:408-607), ``get_current_audio_length`` (:618-621), the same
 stored fields, error types and the three return shapes.
 
+Provenance of this file: the host-side control flow of ``generate()`` / ``preprocess_reference()`` is a condensed restatement of the
+reference's, statement for statement where its behaviour is observable (local names, the duration rule, the progress prints, the rms and
+cross-fade arithmetic) -- the north star asks for an identical API and identical host behaviour, and these lines have one spelling.  Nothing
+the reference computes on the model path is reused: the backbone, sampler, vocoder, mel and resampling all run in libf5hip.
+
 Differences forced by the offline, ROCm-only image (each raises instead of silently approximating):
   * no Whisper ASR is initialised (reference :100 downloads openai/whisper-large-v3-turbo): ``ref_text`` must be given;
   * checkpoints and the Vocos weights must be local files (reference :125 / utils_infer.py:110-112 fetch from the hub);

@@ -112,6 +112,7 @@ class DiT(nn.Module):
         self._native_versions = None
         self._plans = []
         self._seen_shapes = {}
+        self._fallbacks_seen = {}
         self.register_load_state_dict_post_hook(lambda module, _keys: module._drop_native())
 
     # ------------------------------------------------------------------ native handle management
@@ -257,7 +258,26 @@ class DiT(nn.Module):
         _lib.check(lib.f5_sample(plan, B, N, _lib.ptr(cond), _lib.ptr(ids), ids.shape[1], _lib.ptr(lens32), _lib.ptr(dur32), _lib.ptr(y0),
                                  C.c_void_p(tg.data_ptr()), steps, float(cfg_strength), meth, _lib.ptr(out), _lib.ptr(traj),
                                  int(bool(use_graph)), _lib.stream_ptr()), "sample")
+        if self.precision == _lib.F5_PREC_BF16:
+            # fp16 residual-stream range guard (include/f5hip.h, plan option "residual_guard"): the library repeated the loop with fp32
+            # residual storage when an activation reached fp16's range, and keeps fp32 storage for this plan; say so once per event
+            n = C.c_int(0)
+            _lib.check(lib.f5_plan_get_option(plan, b"residual_fallbacks", C.byref(n)), "plan_get_option")
+            if n.value > self._fallbacks_seen.get(plan.value, 0):
+                self._fallbacks_seen[plan.value] = n.value
+                import warnings
+                warnings.warn("libf5hip: the residual stream left the fp16 range (|x| >= 65504 or NaN); sample() was repeated with fp32 residual "
+                              "storage, which this plan keeps from now on", RuntimeWarning, stacklevel=2)
         return out, traj
+
+    def residual_fallbacks(self):
+        """Number of sample() calls (over the live plans) that the library repeated with fp32 residual storage."""
+        lib, total = _lib.load(), 0
+        for _, h in self._plans:
+            n = C.c_int(0)
+            _lib.check(lib.f5_plan_get_option(h, b"residual_fallbacks", C.byref(n)), "plan_get_option")
+            total += n.value
+        return total
 
     def set_tap(self, plan, name, dst):
         _lib.check(_lib.load().f5_plan_set_tap(plan, None if name is None else name.encode(), _lib.ptr(dst)))

@@ -30,7 +30,10 @@
 extern "C" {
 #endif
 
-#define F5HIP_VERSION 200 /* 0.2.0 */
+/* the library is built with -fvisibility=hidden: only the entry points declared here are exported */
+#define F5_API __attribute__((visibility("default")))
+
+#define F5HIP_VERSION 300 /* 0.3.0 */
 
 /* error codes */
 #define F5_OK 0
@@ -78,28 +81,28 @@ typedef struct f5_dit_config {
 #define F5_ROPE_ADJACENT 0  /* frequency j turns features (2j, 2j+1): rotate_half on '... (d r) -> ... d r', r = 2 (default) */
 #define F5_ROPE_HALF_SPLIT 1 /* frequency j turns features (j, j+32): rotate_half on the two halves of the head (GPT-NeoX form) */
 
-const char* f5_last_error(void);
-int f5_version(void);
+F5_API const char* f5_last_error(void);
+F5_API int f5_version(void);
 /* number of usable gfx950 devices; name_out (>= 64 bytes, may be NULL) receives the arch string of device 0 */
-int f5_device_count(char* name_out);
+F5_API int f5_device_count(char* name_out);
 
 /* ------------------------------------------------------------------ model (weights resident in HBM) */
-int f5_model_create(const f5_dit_config* cfg, f5_model_t* out);
+F5_API int f5_model_create(const f5_dit_config* cfg, f5_model_t* out);
 /* name = DiT.state_dict() key, data = contiguous host fp32, shape as in the checkpoint.
  * Unknown names return F5_EINVAL (callers pass strict=False semantics by skipping names themselves). */
-int f5_model_set_tensor(f5_model_t m, const char* name, const float* host_data, const int64_t* shape, int ndim);
+F5_API int f5_model_set_tensor(f5_model_t m, const char* name, const float* host_data, const int64_t* shape, int ndim);
 /* returns 1/0 whether `name` is a tensor the model expects (and its element count in *numel if non-NULL) */
-int f5_model_has_tensor(f5_model_t m, const char* name, int64_t* numel);
+F5_API int f5_model_has_tensor(f5_model_t m, const char* name, int64_t* numel);
 /* builds the fused device layouts (QKV concat, split input projection, rearranged grouped-conv taps, bf16 copies) */
-int f5_model_finalize(f5_model_t m);
-int f5_model_destroy(f5_model_t m);
+F5_API int f5_model_finalize(f5_model_t m);
+F5_API int f5_model_destroy(f5_model_t m);
 
 /* ------------------------------------------------------------------ plan (workspace for one (batch, seq) bucket) */
 /* max_batch = utterances per call (CFG doubling is internal), max_seq = frames N, max_evals = network
  * evaluations times held at once (steps for euler, 2*steps for midpoint). */
-int f5_plan_create(f5_model_t m, int max_batch, int max_seq, int max_evals, f5_plan_t* out);
-int f5_plan_destroy(f5_plan_t p);
-int64_t f5_plan_workspace_bytes(f5_plan_t p);
+F5_API int f5_plan_create(f5_model_t m, int max_batch, int max_seq, int max_evals, f5_plan_t* out);
+F5_API int f5_plan_destroy(f5_plan_t p);
+F5_API int64_t f5_plan_workspace_bytes(f5_plan_t p);
 
 /* CFM.sample (cfm.py:82-208) after text->ids and duration resolution:
  *   cond      dev f32 [B, N, mel]  prompt mel zero-padded to N (NOT yet masked by lens: the kernel applies cfm.py:148-150)
@@ -111,30 +114,31 @@ int64_t f5_plan_workspace_bytes(f5_plan_t p);
  *   out       dev f32 [B, N, mel]  where(cond_mask, cond, y(1)) (cfm.py:200-202)
  *   trajectory dev f32 [steps+1, B, N, mel] or NULL
  * use_graph != 0 replays a hipGraph captured for this exact (B, N, nt, steps, method, cfg on/off, mask on/off). */
-int f5_sample(f5_plan_t p, int B, int N, const float* cond, const int32_t* text, int nt, const int32_t* lens,
+F5_API int f5_sample(f5_plan_t p, int B, int N, const float* cond, const int32_t* text, int nt, const int32_t* lens,
               const int32_t* durations, const float* y0, const float* tgrid_host, int steps, float cfg_strength,
               int ode_method, float* out, float* trajectory, int use_graph, f5_stream_t stream);
 
 /* TextEmbedding.forward (dit.py:49-79): text ids [B, nt] (-1 padded) -> dev f32 [B, N, text_dim] */
-int f5_text_embed(f5_plan_t p, int B, int N, const int32_t* text, int nt, int drop_text, float* out, f5_stream_t stream);
+F5_API int f5_text_embed(f5_plan_t p, int B, int N, const int32_t* text, int nt, int drop_text, float* out, f5_stream_t stream);
 
 /* DiT.forward (dit.py:185-233) for one branch:
  *   x, cond dev f32 [B, N, mel]; text_embed dev f32 [B, N, text_dim] (from f5_text_embed; the Python module owns the
  *   cond/uncond cache of dit.py:202-210); time dev f32 [B]; mask dev u8 [B, N] or NULL; out dev f32 [B, N, mel]. */
-int f5_dit_forward(f5_plan_t p, int B, int N, const float* x, const float* cond, const float* text_embed,
+F5_API int f5_dit_forward(f5_plan_t p, int B, int N, const float* x, const float* cond, const float* text_embed,
                    const float* time, int drop_audio_cond, const uint8_t* mask, float* out, f5_stream_t stream);
 
 /* debug/parity taps: after the next f5_dit_forward / f5_sample evaluation, copy the named internal stage
  * (converted to f32, row-major [rows, cols]) into `dst` (dev f32).  Names: "t_emb", "input_embed",
  * "blk<i>.n1", "blk<i>.attn", "blk<i>.out", "final_norm".  Pass dst = NULL to clear all taps. */
-int f5_plan_set_tap(f5_plan_t p, const char* stage, float* dst);
+F5_API int f5_plan_set_tap(f5_plan_t p, const char* stage, float* dst);
 /* in-situ timing of the dominant kernel: between begin and end, every fused-QKV GEMM launch of (eager) f5_sample /
  * f5_dit_forward calls on this plan is bracketed by a HIP event pair on the caller's stream; end synchronises the stream and
  * returns the mean device time per launch.  Used by bench.py for roofline.achieved. */
-int f5_plan_timing_begin(f5_plan_t p, int max_launches);
-int f5_plan_timing_end(f5_plan_t p, float* avg_ms, int* launches, f5_stream_t stream);
+F5_API int f5_plan_timing_begin(f5_plan_t p, int max_launches);
+F5_API int f5_plan_timing_end(f5_plan_t p, float* avg_ms, int* launches, f5_stream_t stream);
 /* the same measurement for every kernel of a DiT evaluation: after f5_plan_timing_end, mean device time per launch of call site
- * `site` (max_launches of f5_plan_timing_begin counts event pairs over ALL sites: 6 per block + 3 per evaluation). */
+ * `site` (max_launches of f5_plan_timing_begin counts event pairs over ALL sites: 7 per block + 3 per evaluation; when the pool runs out
+ * f5_plan_timing_end fails with F5_ESTATE instead of returning means over the early launches only). */
 #define F5_SITE_QKV 0   /* fused QKV projection + RoPE            modules.py:452-461 */
 #define F5_SITE_ATTN 1  /* scaled-dot-product attention           modules.py:483-497 */
 #define F5_SITE_OUT 2   /* attention out-projection x gate_msa    modules.py:499-501,635 */
@@ -145,10 +149,17 @@ int f5_plan_timing_end(f5_plan_t p, float* avg_ms, int* launches, f5_stream_t st
 #define F5_SITE_CONV 7  /* grouped Conv1d(k=31) + Mish (x2)       modules.py:167-190 */
 #define F5_SITE_INPUT 8 /* input projection of the noisy mel      dit.py:88-96 */
 #define F5_SITE_COUNT 9
-int f5_plan_timing_site(f5_plan_t p, int site, float* avg_ms, int* launches);
+F5_API int f5_plan_timing_site(f5_plan_t p, int site, float* avg_ms, int* launches);
 /* kernel selection for A/B runs: key "gemm_kernel" / "attn_kernel"; value 0 = reference tile kernels, 1 or -1 = tuned
- * kernels wherever they support the problem (default).  Drops any captured graphs. */
-int f5_plan_set_option(f5_plan_t p, const char* key, int value);
+ * kernels wherever they support the problem (default).  Drops any captured graphs.
+ * Residual-stream storage of the bf16 mode: key "residual_f16": 1 = fp16 (saturating), 0 = fp32, -1 = the process-wide
+ * knob (default: fp16); key "residual_guard" (default 1): f5_sample reads, after the ODE loop, the flag word the LayerNorm passes raise when
+ * an element of the fp16 stream reaches +-65504 or is NaN, repeats the loop with fp32 storage and keeps fp32 storage for this plan
+ * (f5_sample then synchronises the stream once per call; 0 = no read, fully asynchronous, clipping goes unnoticed). */
+F5_API int f5_plan_set_option(f5_plan_t p, const char* key, int value);
+/* reads an option back; besides the keys above: "residual_fallbacks" = f5_sample calls of this plan that were repeated with fp32 residual
+ * storage because the range guard fired ("residual_f16" then reads 0). */
+F5_API int f5_plan_get_option(f5_plan_t p, const char* key, int* value);
 
 /* ------------------------------------------------------------------ duration predictor
  * Replaces DurationPredictor.forward / .phoneme_forward (reference model/duration_predictor.py:28-46 / :48-68) as called from
@@ -161,14 +172,14 @@ typedef struct f5_duration_weights {
 } f5_duration_weights;
 /* tokens i32 [batch, nt] (pad -1), add_one = 1 for forward() (ids shifted so that 0 is the filler), 0 for phoneme_forward();
  * mask i32 [batch, nt] (1 = real token); scratch f32 [2 * batch * filter_channels * nt]; out f32 [batch, nt] = log-durations * mask. */
-int f5_duration_predict(const f5_duration_weights* w, int batch, int nt, const int32_t* tokens, int add_one, const int32_t* mask,
+F5_API int f5_duration_predict(const f5_duration_weights* w, int batch, int nt, const int32_t* tokens, int add_one, const int32_t* mask,
                         float* scratch, float* out, f5_stream_t stream);
 
 /* ------------------------------------------------------------------ per-op entry points (parity tests, micro-benchmarks) */
 /* out[M,N] = A[M,K] @ W[N,K]^T + bias ; A/W/out f32 dev; computed through the precision's GEMM kernel
  * (bf16: inputs rounded to bf16 on device, MFMA, f32 accumulate).  act: 0 none, 1 gelu-tanh, 2 gelu-erf, 3 mish.
  * kernel: 0 = reference tile kernel, 1 = tuned 256x256 LDS-DMA kernel (bf16 only; shapes must be tile multiples). */
-int f5_op_linear(int precision, int kernel, int M, int N, int K, const float* A, const float* W, const float* bias, int act,
+F5_API int f5_op_linear(int precision, int kernel, int M, int N, int K, const float* A, const float* W, const float* bias, int act,
                  float* out, f5_stream_t stream);
 /* One DiT block linear with the fused store epilogue the sampler uses for it (bf16 path; output converted back to f32):
  *   epi 0: out = act(A W^T + b)                                      FeedForward first linear, reference model/modules.py:258-264
@@ -177,32 +188,32 @@ int f5_op_linear(int precision, int kernel, int M, int N, int K, const float* A,
  *   epi 4: out = rope(A W^T + b): fused QKV projection (N = 3*inner), x_transformers rotary on adjacent pairs of the q and k columns
  *          of the first rope_heads heads, modules.py:452-461; rope f32 [seq][32][2] (cos, sin), token position = m % seq
  * kernel: 0 = reference tile kernel, 1 = tuned kernels.  All pointers are device pointers. */
-int f5_op_linear_fused(int kernel, int epi, int M, int N, int K, const float* A, const float* W, const float* bias, int act,
+F5_API int f5_op_linear_fused(int kernel, int epi, int M, int N, int K, const float* A, const float* W, const float* bias, int act,
                        const float* gate, const uint8_t* rowmask, const float* rope, int rope_heads, int seq, float* out,
                        f5_stream_t stream);
 /* LayerNorm(eps 1e-6, no affine) * (1 + scale) + shift ; x f32 [rows, dim]; scale/shift f32 [dim] */
-int f5_op_layernorm_modulate(int rows, int dim, const float* x, const float* scale, const float* shift, float* out,
+F5_API int f5_op_layernorm_modulate(int rows, int dim, const float* x, const float* scale, const float* shift, float* out,
                              f5_stream_t stream);
 /* multi-head attention on packed projections: qkv f32 [B, N, 3, H, 64] (already RoPE'd), mask u8 [B,N] or NULL
  * -> out f32 [B, N, H*64].  kernel: 0 = reference kernel, 1 = tuned flash kernel (bf16). */
-int f5_op_attention(int precision, int kernel, int B, int N, int H, const float* qkv, const uint8_t* mask, float* out,
+F5_API int f5_op_attention(int precision, int kernel, int B, int N, int H, const float* qkv, const uint8_t* mask, float* out,
                     f5_stream_t stream);
 /* ConvPositionEmbedding (modules.py:167-190): x f32 [B, N, dim] -> mish(conv(mish(conv(x)))) ; weights f32
  * [dim, dim/16, 31] + bias [dim] (two layers) */
-int f5_op_conv_pos_embed(int precision, int B, int N, int dim, const float* x, const float* w0, const float* b0,
+F5_API int f5_op_conv_pos_embed(int precision, int B, int N, int dim, const float* x, const float* w0, const float* b0,
                          const float* w1, const float* b1, float* out, f5_stream_t stream);
 
 /* in-process kernel timing for the roofline leg of bench.py: `iters` back-to-back launches of ONE kernel bracketed by HIP
  * events on `stream`, random bf16 operands; *ms_avg = mean device time per launch.
  * site: 0 fused QKV projection + RoPE, 1 FF1 + GELU-tanh, 2 FF2 + gated residual, 3 attention out-projection + gated residual. */
-int f5_bench_gemm_site(int kernel, int site, int rows, int seq, int dim, int heads, int ff_inner, int iters, float* ms_avg,
+F5_API int f5_bench_gemm_site(int kernel, int site, int rows, int seq, int dim, int heads, int ff_inner, int iters, float* ms_avg,
                        f5_stream_t stream);
-int f5_bench_attention(int kernel, int B, int N, int H, int iters, float* ms_avg, f5_stream_t stream);
+F5_API int f5_bench_attention(int kernel, int B, int N, int H, int iters, float* ms_avg, f5_stream_t stream);
 /* Sustained rate of a register-resident v_mfma_f32_16x16x32_bf16 stream on every CU (no memory traffic): random_operands = 0 zeros
  * (clock-limited), 1 pseudo-random bf16 values (power-limited: what a dense bf16 GEMM can approach on this device). */
-int f5_bench_mfma_rate(int random_operands, float* tflops, f5_stream_t stream);
+F5_API int f5_bench_mfma_rate(int random_operands, float* tflops, f5_stream_t stream);
 /* process-wide kernel tuning knobs for A/B measurements ("gemm_variant": main-loop schedule of the tuned GEMM) */
-int f5_tuning_set(const char* key, int value);
+F5_API int f5_tuning_set(const char* key, int value);
 
 /* ------------------------------------------------------------------ Vocos vocoder (plug point B) */
 typedef struct f5_vocos_config {
@@ -213,16 +224,16 @@ typedef struct f5_vocos_config {
     int32_t n_fft;     /* 1024 */
     int32_t hop;       /* 256 */
 } f5_vocos_config;
-int f5_vocoder_create(const f5_vocos_config* cfg, f5_vocoder_t* out);
-int f5_vocoder_set_tensor(f5_vocoder_t v, const char* name, const float* host_data, const int64_t* shape, int ndim);
-int f5_vocoder_has_tensor(f5_vocoder_t v, const char* name, int64_t* numel);
-int f5_vocoder_finalize(f5_vocoder_t v);
-int f5_vocoder_destroy(f5_vocoder_t v);
+F5_API int f5_vocoder_create(const f5_vocos_config* cfg, f5_vocoder_t* out);
+F5_API int f5_vocoder_set_tensor(f5_vocoder_t v, const char* name, const float* host_data, const int64_t* shape, int ndim);
+F5_API int f5_vocoder_has_tensor(f5_vocoder_t v, const char* name, int64_t* numel);
+F5_API int f5_vocoder_finalize(f5_vocoder_t v);
+F5_API int f5_vocoder_destroy(f5_vocoder_t v);
 /* Vocos.decode: mel dev f32 [B, n_mels, T] -> wave dev f32 [B, (T-1)*hop] */
-int f5_vocoder_decode(f5_vocoder_t v, int B, int T, const float* mel, float* wave, f5_stream_t stream);
+F5_API int f5_vocoder_decode(f5_vocoder_t v, int B, int T, const float* mel, float* wave, f5_stream_t stream);
 /* ISTFT head alone (for the roofline measurement): spec dev f32 [B, T, n_fft+2] (head.out activations:
  * log-magnitude | phase) -> wave dev f32 [B, (T-1)*hop] */
-int f5_vocoder_istft_head(f5_vocoder_t v, int B, int T, const float* head_out, float* wave, f5_stream_t stream);
+F5_API int f5_vocoder_istft_head(f5_vocoder_t v, int B, int T, const float* head_out, float* wave, f5_stream_t stream);
 
 /* ------------------------------------------------------------------ reference-audio front-end on the device
  * Replaces the two torchaudio transforms of the path:
@@ -238,10 +249,10 @@ typedef struct f5_mel_config {
     int32_t n_mels;      /* 100 */
     int32_t sample_rate; /* 24000: the filterbank spans 0 .. sample_rate / 2 */
 } f5_mel_config;
-int f5_frontend_create(const f5_mel_config* cfg, f5_frontend_t* out);
-int f5_frontend_destroy(f5_frontend_t h);
-int f5_frontend_mel(f5_frontend_t h, int B, int nw, const float* wave, float* mel, f5_stream_t stream);
-int f5_frontend_resample(f5_frontend_t h, int B, int n, int orig_freq, int new_freq, const float* wave, float* out, f5_stream_t stream);
+F5_API int f5_frontend_create(const f5_mel_config* cfg, f5_frontend_t* out);
+F5_API int f5_frontend_destroy(f5_frontend_t h);
+F5_API int f5_frontend_mel(f5_frontend_t h, int B, int nw, const float* wave, float* mel, f5_stream_t stream);
+F5_API int f5_frontend_resample(f5_frontend_t h, int B, int n, int orig_freq, int new_freq, const float* wave, float* out, f5_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -333,6 +333,53 @@ def mel_spectrogram(wave, n_fft=1024, hop=256, win=1024, n_mels=100, sr=24000):
     return mel.clamp(min=1e-5).log()  # [b, n_mels, nw//hop + 1]
 
 
+# ----------------------------------------------------------------------------- f3: sample-rate conversion (unpinned: torchaudio absent)
+def resample(wave, orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99):
+    """torchaudio.transforms.Resample(orig, new) with its defaults (resampling_method "sinc_interp_hann", width 6, rolloff 0.99), the call
+    of infer/f5tts_wrapper.py:338-341 / utils_infer.py:431-433, restated from the published algorithm (torchaudio.functional.functional
+    ``_get_sinc_resample_kernel`` + ``_apply_sinc_resample_kernel``) as a DIRECT polyphase sum in float64 numpy -- on purpose not the
+    strided conv1d the product's host branch uses, so that the two agree only if both are right:
+
+        g = gcd; orig, new = orig/g, new/g;  base = min(orig, new) * rolloff;  width = ceil(lpw * orig / base)
+        out[i * new + j] = sum_{k = 0}^{2 width + orig - 1}  xpad[i * orig + k] * h_j[k]          xpad = x padded (width, width + orig)
+        h_j[k] = sinc(pi * t) * cos(pi * t / (2 lpw))^2 * base / orig,   t = clamp(((k - width) / orig - j / new) * base, -lpw, lpw)
+        length = ceil(new * n / orig)
+
+    wave: float tensor [..., n] -> float32 tensor [..., length]."""
+    import numpy as np
+    if int(orig_freq) == int(new_freq):
+        return wave
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    lpw = float(lowpass_filter_width)
+    base = min(orig, new) * rolloff
+    width = int(math.ceil(lpw * orig / base))
+    taps = 2 * width + orig
+    k = np.arange(taps, dtype=np.float64)
+    h = np.empty((new, taps), dtype=np.float64)
+    for j in range(new):
+        t = np.clip(((k - width) / orig - j / new) * base, -lpw, lpw)
+        win = np.cos(t * math.pi / lpw / 2.0) ** 2
+        tp = t * math.pi
+        with np.errstate(invalid="ignore", divide="ignore"):
+            sinc = np.where(tp == 0.0, 1.0, np.sin(tp) / tp)
+        h[j] = sinc * win * (base / orig)
+    h = h.astype(np.float32).astype(np.float64)  # torchaudio casts the kernel to the waveform dtype (float32) before convolving
+    x = wave.detach().cpu().to(torch.float64).numpy()
+    shape = x.shape
+    x = x.reshape(-1, shape[-1])
+    n = x.shape[-1]
+    xp = np.pad(x, ((0, 0), (width, width + orig)))
+    steps = (xp.shape[-1] - taps) // orig + 1
+    target = int(math.ceil(new * n / orig))
+    out = np.zeros((x.shape[0], steps * new), dtype=np.float64)
+    for i in range(steps):
+        seg = xp[:, i * orig: i * orig + taps]  # [rows, taps]
+        out[:, i * new: (i + 1) * new] = seg @ h.T
+    out = out[:, :target].reshape(shape[:-1] + (target,))
+    return torch.from_numpy(out.astype(np.float32))
+
+
 # ----------------------------------------------------------------------------- a22: Vocos (unpinned)
 def vocos_backbone(V, mel):
     """vocos VocosBackbone (source absent; restated): conv k7 -> LN -> 8x ConvNeXt(layer-scale) -> LN."""

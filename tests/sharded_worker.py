@@ -1,5 +1,7 @@
 """Rank program of tests/test_gpu_sharded.py (not a test): one process per rank, started by torch.distributed.run, every rank on the
-GPU it is given (LOCAL_RANK modulo the visible devices -- two ranks share the one GPU of a test box), `gloo` for the gather.
+GPU it is given (LOCAL_RANK modulo the visible devices -- two ranks share the one GPU of a test box), `gloo` for the gather; with
+F5_TEST_BACKEND=nccl (world size 1 on a one-GPU box: RCCL refuses two ranks on one device) the SAME collectives run over RCCL: the payload
+all_gather on device tensors, an all_gather_object, the MAX all_reduce and the barriers bench.py issues.
 Runs the REAL CFM.sample of a tiny DiT through eraxvif5tts_amd.eval.sharded.sample_sharded and saves rank 0's gathered list."""
 import os
 import sys
@@ -41,11 +43,26 @@ def main():
     from eraxvif5tts_amd.eval.sharded import sample_sharded
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
-    dist.init_process_group("gloo")
+    backend = os.environ.get("F5_TEST_BACKEND", "gloo")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+    else:
+        dist.init_process_group("gloo")
     cfm = make_cfm()
-    outs = sample_sharded(cfm.sample, make_batches(), device="cpu" if dist.get_backend() == "gloo" else "cuda")
+    dev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+    outs = sample_sharded(cfm.sample, make_batches(), device=dev, force_collective=True)
+    extra = {}
+    if backend == "nccl":  # the other collectives of bench.py's multi-GPU leg, and the metadata exchange of a bare gather_utterances
+        from eraxvif5tts_amd.eval.sharded import gather_utterances
+        t = torch.tensor([1.5 + dist.get_rank()], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        names = [None] * dist.get_world_size()
+        dist.all_gather_object(names, f"rank{dist.get_rank()}:{torch.cuda.get_device_name()}")
+        again = gather_utterances([o.cuda() for o in outs], [o.shape[0] for o in outs], 100, "cuda", force_collective=True)  # metadata by all_gather_object
+        extra = {"max": float(t.item()), "names": names, "regather_equal": all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(again, outs)),
+                 "backend": dist.get_backend()}
     if dist.get_rank() == 0:
-        torch.save({"world": dist.get_world_size(), "outs": [o.cpu() for o in outs]}, sys.argv[1])
+        torch.save({"world": dist.get_world_size(), "outs": [o.cpu() for o in outs], **extra}, sys.argv[1])
     dist.barrier()
     dist.destroy_process_group()
 

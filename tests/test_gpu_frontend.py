@@ -1,5 +1,5 @@
 """Reference-audio front-end on the device (csrc/frontend.hip through the C ABI): log-mel spectrogram and sample-rate conversion against the
-CPU restatements (oracle/cpu_ref.mel_spectrogram = torch.stft + HTK filterbank; infer/audio.resample on a host tensor = torchaudio's sinc FIR).
+CPU restatements (oracle/cpu_ref.mel_spectrogram = torch.stft + HTK filterbank; oracle/cpu_ref.resample = torchaudio's sinc FIR as a float64 polyphase sum).
 
 Tolerances: the DFT runs on the fp32-input MFMA (exact fp32 products, fp32 sums over 1024 terms): |log-mel difference| <= 2e-3 wherever the mel
 energy is above the 1e-5 floor by a factor of 10 (below it, the log of a difference of rounding noise is meaningless); resampling rel-L2 <= 1e-5."""
@@ -57,13 +57,17 @@ def test_mel_inside_sample_uses_the_device_path():
 
 
 @pytest.mark.parametrize("orig,new", [(16000, 24000), (44100, 24000), (48000, 24000), (22050, 24000), (24000, 24000)])
-def test_resample_matches_host_restatement(orig, new):
+def test_resample_matches_oracle(orig, new):
+    """f5_frontend_resample (device tensor) AND the package's host branch against oracle/cpu_ref.resample, the float64 polyphase restatement
+    of torchaudio's sinc_interp_hann resampler (width 6, rolloff 0.99; f5tts_wrapper.py:338-341)."""
     from eraxvif5tts_amd.infer import audio
     g = torch.Generator().manual_seed(orig)
     n = 12345
     t = torch.arange(n) / orig
     wav = torch.stack([0.5 * torch.sin(2 * math.pi * 440 * t) + 0.1 * torch.randn(n, generator=g), 0.2 * torch.randn(n, generator=g)])
-    ref = audio.resample(wav, orig, new)           # host tensor: the conv1d restatement of torchaudio's kernel
+    ref = cpu_ref.resample(wav, orig, new)
+    host = audio.resample(wav, orig, new)              # host tensor: strided conv1d form
     out = audio.resample(wav.cuda(), orig, new).cpu()  # device tensor: f5_frontend_resample
-    assert out.shape == ref.shape == (2, math.ceil(new // math.gcd(orig, new) * n / (orig // math.gcd(orig, new))))
+    assert out.shape == host.shape == ref.shape == (2, math.ceil(new // math.gcd(orig, new) * n / (orig // math.gcd(orig, new))))
     assert rel_l2(out, ref) < 1e-5
+    assert rel_l2(host, ref) < 1e-5

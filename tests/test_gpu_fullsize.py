@@ -119,11 +119,44 @@ def test_true_depth_bf16_sampler_stays_within_tolerance_of_fp32_mode():
     assert torch.isfinite(outs["bf16"]).all() and err < 2e-2
 
 
+def test_bench_path_equal_durations_full_batch_against_fp32_mode():
+    """The exact path `bench.py` times at C2: 32 utterances x 1024 frames, ALL durations equal, so CFM.sample asks for the unmasked kernels
+    (attn_wide_kernel<false>, mask-free GEMM epilogues, persistent 256 x 256 tiles at 65 536 token rows), bf16, hipGraph replay.  Utterances
+    3 and 17 of that batch against the fp32 parity mode run on those two utterances alone (rows of a batch are independent), NFE 2, CFG 2;
+    and the eager launch against the graph replay, bit for bit."""
+    import bench
+    from eraxvif5tts_amd.model import CFM, DiT
+    B, N, pick = 32, 1024, [3, 17]
+    cond, text, lens, dur = bench.synth_batch(B, N, "cuda", seed=21)
+    assert int(dur.min()) == int(dur.max()) == N
+    y0 = torch.randn(B, N, 100, generator=torch.Generator().manual_seed(22))
+    kw = dict(steps=2, cfg_strength=2.0, sway_sampling_coef=-1.0, return_trajectory=False)
+    torch.manual_seed(1234)
+    model = bench.synth_weights(DiT(**bench.BASE_ARCH, text_num_embeds=bench.VOCAB, mel_dim=100, precision="bf16"), seed=0)
+    cfm = CFM(transformer=model, mel_spec_kwargs={"mel_spec_type": "vocos"}).cuda()
+    full, _ = cfm.sample(cond=cond, text=text, duration=dur, lens=lens, y0=y0, use_graph=True, **kw)
+    eager, _ = cfm.sample(cond=cond, text=text, duration=dur, lens=lens, y0=y0, use_graph=False, **kw)
+    assert torch.isfinite(full).all() and torch.equal(full, eager)
+    full = full[pick].cpu()
+    del cfm, model, eager
+    torch.cuda.empty_cache()
+    torch.manual_seed(1234)
+    model = bench.synth_weights(DiT(**bench.BASE_ARCH, text_num_embeds=bench.VOCAB, mel_dim=100, precision="fp32"), seed=0)
+    cfm = CFM(transformer=model, mel_spec_kwargs={"mel_spec_type": "vocos"}).cuda()
+    ref, _ = cfm.sample(cond=cond[pick], text=text[pick], duration=dur[pick], lens=lens[pick], y0=y0[pick], **kw)
+    n_ref = cond.shape[1]
+    err = rel_l2(full[:, n_ref:], ref[:, n_ref:].cpu())
+    print(f"C2 bench path (32 x 1024, equal durations, bf16 graph) vs fp32 mode on utterances {pick}: rel-L2 {err:.3e}")
+    assert err < 2e-2
+    assert torch.equal(full[:, :n_ref], cond[pick].cpu())  # prompt frames are the conditioning itself (cfm.py:200-202)
+
+
 def test_fp16_residual_stream_against_fp32_residual_stream():
     """The bf16 production mode stores the residual stream in fp16 from the first block on (the reference's GPU path keeps the whole model
     in fp16: utils_infer.py:184-193); `residual_f16 = 0` keeps it in fp32.  F5TTS_Base, N = 512, NFE 8, CFG 2: the two against each other
-    and each against the fp32 parity mode; and the same network with its input scaled so that the residual stream runs 300 x larger
-    (fp16's 11-bit mantissa is relative: the deviation must not grow)."""
+    and each against the fp32 parity mode.  (fp16's RANGE is covered by test_fp16_residual_range_guard_falls_back_to_fp32_storage: a stream
+    that reaches +-65504 makes f5_sample repeat the loop with fp32 storage instead of clipping; this test also asserts that the well-scaled
+    network never trips that guard.)"""
     import bench
     from eraxvif5tts_amd import _lib
     from eraxvif5tts_amd.model import CFM, DiT
@@ -131,7 +164,7 @@ def test_fp16_residual_stream_against_fp32_residual_stream():
     cond, text, lens, dur = bench.synth_batch(B, N, "cuda", seed=3)
     y0 = torch.randn(B, N, 100, generator=torch.Generator().manual_seed(4))
     n_ref = cond.shape[1]
-    outs = {}
+    outs, fallbacks = {}, 0
     for tag, prec, knob in (("fp32", "fp32", 1), ("bf16_res16", "bf16", 1), ("bf16_res32", "bf16", 0)):
         torch.manual_seed(1234)
         model = bench.synth_weights(DiT(**bench.BASE_ARCH, text_num_embeds=bench.VOCAB, mel_dim=100, precision=prec), seed=0)
@@ -145,6 +178,7 @@ def test_fp16_residual_stream_against_fp32_residual_stream():
         outs[tag] = out[:, n_ref:].cpu()
         del cfm, model
         torch.cuda.empty_cache()
+    assert fallbacks == 0  # no element of the fp16 stream came near +-65504
     e16, e32, ab = rel_l2(outs["bf16_res16"], outs["fp32"]), rel_l2(outs["bf16_res32"], outs["fp32"]), rel_l2(outs["bf16_res16"], outs["bf16_res32"])
     print(f"vs fp32 mode: fp16 residual {e16:.3e}, fp32 residual {e32:.3e}; against each other {ab:.3e}")
     assert torch.isfinite(outs["bf16_res16"]).all()

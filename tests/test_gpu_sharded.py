@@ -47,6 +47,30 @@ def test_two_real_ranks_equal_one_process(tmp_path):
         assert a.shape == b.shape and torch.isfinite(a).all() and torch.equal(a, b.cpu())
 
 
+def test_rccl_backend_runs_the_collectives_at_world_size_one(tmp_path):
+    """RCCL itself (torch.distributed backend "nccl"), on the one GPU a test box has: process-group init with a device id, the payload
+    all_gather of the finished mels on DEVICE tensors, all_gather_object, the MAX all_reduce and the barriers -- every call the 8-GPU run
+    makes -- at world size 1 (RCCL refuses two ranks on one device).  The gathered list must equal the plain single-process result."""
+    from eraxvif5tts_amd import _lib
+    from eraxvif5tts_amd.eval.sharded import sample_sharded
+    _lib.require_gpu()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import sharded_worker as SW
+    out_file = str(tmp_path / "rccl.pt")
+    env = _env()
+    env["F5_TEST_BACKEND"] = "nccl"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(ROOT, "tests", "sharded_worker.py"), out_file]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got = torch.load(out_file, weights_only=True)
+    assert got["world"] == 1 and got["backend"] == "nccl" and got["max"] == 1.5 and got["regather_equal"] and len(got["names"]) == 1
+    single = sample_sharded(SW.make_cfm().sample, SW.make_batches(), device="cuda")
+    assert len(got["outs"]) == len(single) == 9
+    for a, b in zip(got["outs"], single):
+        assert a.shape == b.shape and torch.equal(a, b.cpu())
+
+
 def test_bench_gpus_flag_launches_the_ranks():
     """`python bench.py --gpus 2` with no launcher around it: the parent starts two ranks (before touching the GPU itself) and relays
     rank 0's line; strong scaling splits the SAME utterances.  (gloo stands in for RCCL: both ranks share this box's one GPU.)"""

@@ -84,10 +84,12 @@ def test_b1_midpoint_and_cfg0():
         assert rel_l2(out, z["out_" + tag]) < TOL
 
 
-def test_true_size_base_forward():
-    """F5TTS_Base dims (1024 x 22 layers, pe_attn_head=1): weights regenerated from the seed on this machine."""
-    z = load_golden("base_fwd")
-    cfg = dict(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, text_mask_padding=False, conv_layers=4, pe_attn_head=1)
+@pytest.mark.parametrize("fixture,v1", [("base_fwd", False), ("v1_fwd", True)])
+def test_true_size_base_forward(fixture, v1):
+    """F5TTS_Base (pe_attn_head=1) and F5TTS_v1_Base (all-head RoPE, text mask padding) dims, 1024 x 22 layers: weights regenerated from the
+    seed on this machine, outputs from the reference's own DiT.forward."""
+    z = load_golden(fixture)
+    cfg = dict(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, text_mask_padding=v1, conv_layers=4, pe_attn_head=None if v1 else 1)
     W = cpu_ref.random_dit_weights(cfg, int(z["vocab"]), seed=int(z["seed"]))
     for drop, key in ((False, "out_c"), (True, "out_u")):
         out = cpu_ref.dit_forward(W, cfg, torch.from_numpy(z["x"]), torch.from_numpy(z["cond"]), torch.from_numpy(z["text"]),

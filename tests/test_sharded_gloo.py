@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from eraxvif5tts_amd.eval.sharded import sample_sharded, split_between_processes
+from eraxvif5tts_amd.eval.sharded import gather_utterances, sample_sharded, split_between_processes
 
 
 def _fake_sample(cond, text, duration, lens, steps=2, **_):
@@ -35,6 +35,10 @@ def _worker(rank, world, rendezvous, q):
     # file rendezvous: no port to race for with other processes of the host
     dist.init_process_group("gloo", init_method="file://" + rendezvous, rank=rank, world_size=world)
     outs = sample_sharded(_fake_sample, _batches(), device="cpu")
+    # a bare gather_utterances (no batch list to derive the ragged metadata from): ONE all_gather_object + the payload all_gather
+    local = sample_sharded(_fake_sample, _batches(), device="cpu", gather=False)
+    again = gather_utterances(local, [t.shape[0] for t in local], 100, "cpu")
+    assert len(again) == len(outs) and all(torch.equal(a, b) for a, b in zip(again, outs))
     # plain numpy arrays through the queue: a torch tensor travels as a shared-memory handle that dies with this process if the parent is
     # slow to pick it up
     q.put((rank, [o.numpy().copy() for o in outs]))
