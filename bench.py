@@ -390,14 +390,22 @@ def main():
             dist.all_gather(gathered, pad)  # the only collective of the path: finished mels over RCCL/xGMI
         return out
 
-    for _ in range(args.warmup):
+    debug = bool(os.environ.get("F5_BENCH_DEBUG"))
+    if debug:
+        import warnings
+        warnings.simplefilter("always")
+    for i in range(args.warmup):
         step()
+        if debug:
+            sys.stderr.write(f"[debug] warm-up {i}: residual fallbacks so far {model.residual_fallbacks()}\n")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         out = step()
+        if debug:
+            sys.stderr.write(f"[debug] step {i}: residual fallbacks so far {model.residual_fallbacks()}\n")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -70,6 +70,8 @@ _PROTOS = {
     "f5_bench_attention": (_I, [_I, _I, _I, _I, _I, C.POINTER(C.c_float), _P]),
     "f5_bench_mfma_rate": (_I, [_I, C.POINTER(C.c_float), _P]),
     "f5_tuning_set": (_I, [C.c_char_p, _I]),
+    "f5_debug_attn_stamps": (_I, [_P]),
+    "f5_debug_gemm_clock": (_I, [_P]),
     "f5_vocoder_create": (_I, [C.POINTER(VocosConfig), C.POINTER(_P)]),
     "f5_vocoder_set_tensor": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I]),
     "f5_vocoder_has_tensor": (_I, [_P, C.c_char_p, C.POINTER(C.c_int64)]),

@@ -38,16 +38,27 @@ template <typename XT> __device__ __forceinline__ void store_res4(XT* p, const f
 // Range guard of the fp16 residual stream (the stores above SATURATE at +-65504): a lane that read, formed or stored an element at or beyond
 // fp16's largest finite value -- or a NaN, which the running sum carries -- raises the plan's flag word; f5_sample reads it after the loop
 // and repeats the call with fp32 residual storage (model.hip).  One compare per row on the common path.
-__device__ __forceinline__ void res_range_guard(unsigned* sat, float amax, float partial_sum) {
+__device__ __forceinline__ void res_range_guard(unsigned* sat, float amax, float partial_sum, int tag = 0, int row = 0) {
     const bool bad = !(amax < 65504.0f) || !(partial_sum == partial_sum);
-    if (sat && __builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) __hip_atomic_store(sat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (sat && __builtin_amdgcn_ballot_w64(bad) != 0ull) {  // rare: record what was seen (diagnostics read back by f5_plan_get_option)
+        if (bad) {
+            if (amax == amax && amax < 3.0e38f) atomicMax(sat + 1, __float_as_uint(amax));  // word 1: largest finite |element| (float bits)
+            if (!(partial_sum == partial_sum)) __hip_atomic_store(sat + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // word 2: NaN seen
+        }
+        if ((threadIdx.x & 63) == 0) {
+            __hip_atomic_store(sat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicOr(sat + 3, 1u << (tag & 15));         // word 3: which pass (bit 0 hoisted embedding, 1 first / 2 second LayerNorm of a block, 3 final)
+            atomicOr(sat + 4, 1u << ((tag >> 4) & 31));  // word 4: DiT blocks (bit = index mod 32)
+            atomicMax(sat + 5, 0x7fffffffu - (unsigned)row);  // word 5: 0x7fffffff - smallest offending row
+        }
+    }
 }
 
 template <typename TO, int MAXV, int YMODE, bool FULL, typename XI = float, typename XO = float>
 __global__ __launch_bounds__(256) void layernorm_kernel(const XI* x, XO* xo /* may be x itself */, int ldx, int rows, int dim, const TO* __restrict__ y,
                                                         int ldy, const TO* __restrict__ y2, const float* __restrict__ mul, const float* __restrict__ add,
                                                         int mod_bstride, int rows_per_batch, float add_one, TO* __restrict__ out, int ldo,
-                                                        unsigned* sat) {
+                                                        unsigned* sat, int sat_tag) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const XI* x, XO* xo /* m
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
     }
-    if constexpr (sizeof(XI) == 2 || sizeof(XO) == 2) res_range_guard(sat, amax, s);
+    if constexpr (sizeof(XI) == 2 || sizeof(XO) == 2) res_range_guard(sat, amax, s, sat_tag, row);
     const float mean = wave_sum(s) / (float)dim;
     float q = 0.f;
 #pragma unroll
@@ -137,7 +148,7 @@ template <int YMODE>
 __global__ __launch_bounds__(256) void layernorm1024_h_kernel(const _Float16* x, _Float16* xo, int ldx, int rows, const bf16_t* __restrict__ y, int ldy,
                                                               const bf16_t* __restrict__ y2, const float* __restrict__ mul, const float* __restrict__ add,
                                                               int mod_bstride, int rows_per_batch, float add_one, bf16_t* __restrict__ out, int ldo,
-                                                              PrefetchSet pf, unsigned* sat) {
+                                                              PrefetchSet pf, unsigned* sat, int sat_tag) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     // weight prefetch: one dword per 128-byte line is enough to pull the line in; lane l of the wave of row w touches line 64 w + l of every
@@ -195,7 +206,7 @@ __global__ __launch_bounds__(256) void layernorm1024_h_kernel(const _Float16* x,
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         s += (v[i][4] + v[i][5]) + (v[i][6] + v[i][7]);
     }
-    res_range_guard(sat, amax, s);
+    res_range_guard(sat, amax, s, sat_tag, row);
     const float mean = wave_sum(s) / 1024.0f;
     float q = 0.f;
 #pragma unroll
@@ -220,16 +231,16 @@ int g_ln_wide = 1;  // tuning knob ("ln_wide"): 16-byte form of the LayerNorm pa
 
 template <typename TO, int MAXV, typename XI = float, typename XO = float>
 static void ln_launch(const void* x, void* xo, int ldx, int rows, int dim, const void* y, int ldy, const void* y2, int ymode, const float* mul,
-                      const float* add, int mod_bstride, int rows_per_batch, float one, void* out, int ldo, hipStream_t stream, unsigned* sat) {
+                      const float* add, int mod_bstride, int rows_per_batch, float one, void* out, int ldo, hipStream_t stream, unsigned* sat, int sat_tag) {
     dim3 grid(cdiv(rows, 4)), block(256);
 #define F5_LN_CASE(M)                                                                                                                        \
     do {                                                                                                                                     \
         if (dim == MAXV * 256)                                                                                                               \
             hipLaunchKernelGGL((layernorm_kernel<TO, MAXV, M, true, XI, XO>), grid, block, 0, stream, (const XI*)x, (XO*)xo, ldx, rows, dim, \
-                               (const TO*)y, ldy, (const TO*)y2, mul, add, mod_bstride, rows_per_batch, one, (TO*)out, ldo, sat);            \
+                               (const TO*)y, ldy, (const TO*)y2, mul, add, mod_bstride, rows_per_batch, one, (TO*)out, ldo, sat, sat_tag);   \
         else                                                                                                                                 \
             hipLaunchKernelGGL((layernorm_kernel<TO, MAXV, M, false, XI, XO>), grid, block, 0, stream, (const XI*)x, (XO*)xo, ldx, rows, dim, \
-                               (const TO*)y, ldy, (const TO*)y2, mul, add, mod_bstride, rows_per_batch, one, (TO*)out, ldo, sat);            \
+                               (const TO*)y, ldy, (const TO*)y2, mul, add, mod_bstride, rows_per_batch, one, (TO*)out, ldo, sat, sat_tag);   \
     } while (0)
     if (ymode == 0) F5_LN_CASE(0);
     else if (ymode == 1) F5_LN_CASE(1);
@@ -243,7 +254,7 @@ static void ln_launch(const void* x, void* xo, int ldx, int rows, int dim, const
 // the same buffer as xin or another one of the same leading dimension).  fp16 residual storage exists for the bf16 output type only.
 int launch_layernorm_res(int precision_out, const void* xin, int xin_f16, void* xout, int xout_f16, int ldx, int rows, int dim, const void* y, int ldy,
                          const void* y2, int ymode, const float* mul, const float* add, int mod_bstride, int rows_per_batch, int add_one, void* out,
-                         int ldo, hipStream_t stream, const PrefetchSet* prefetch, unsigned* sat) {
+                         int ldo, hipStream_t stream, const PrefetchSet* prefetch, unsigned* sat, int sat_tag) {
     if (rows <= 0) return 0;
     if (dim % 4 != 0 || dim > 2048 || (ldx & 3) || (ldo & 3) || (mod_bstride & 3) || (y && (ldy & 3)))
         return f5_fail(F5_EINVAL, "layernorm: dim=%d unsupported", dim);
@@ -256,9 +267,9 @@ int launch_layernorm_res(int precision_out, const void* xin, int xin_f16, void* 
 #define F5_LN_DIM(TO, XI, XO)                                                                                                                  \
     do {                                                                                                                                       \
         if (dim <= 1024)                                                                                                                       \
-            ln_launch<TO, 4, XI, XO>(xin, xout, ldx, rows, dim, y, ldy, y2, ymode, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream, sat); \
+            ln_launch<TO, 4, XI, XO>(xin, xout, ldx, rows, dim, y, ldy, y2, ymode, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream, sat, sat_tag); \
         else                                                                                                                                   \
-            ln_launch<TO, 8, XI, XO>(xin, xout, ldx, rows, dim, y, ldy, y2, ymode, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream, sat); \
+            ln_launch<TO, 8, XI, XO>(xin, xout, ldx, rows, dim, y, ldy, y2, ymode, mul, add, mod_bstride, rows_per_batch, one, out, ldo, stream, sat, sat_tag); \
     } while (0)
     if (precision_out == F5_PREC_BF16 && xin_f16 && xout_f16 && dim == 1024 && g_ln_wide && !(ldx & 7) && !(ldo & 7) && !(y && (ldy & 7))) {
         dim3 grid(cdiv(rows, 4)), block(256);
@@ -266,7 +277,7 @@ int launch_layernorm_res(int precision_out, const void* xin, int xin_f16, void* 
         if (prefetch) pfs = *prefetch;
 #define F5_LN_W(M)                                                                                                                              \
     hipLaunchKernelGGL((layernorm1024_h_kernel<M>), grid, block, 0, stream, (const _Float16*)xin, (_Float16*)xout, ldx, rows, (const bf16_t*)y, ldy, \
-                       (const bf16_t*)y2, mul, add, mod_bstride, rows_per_batch, one, (bf16_t*)out, ldo, pfs, sat)
+                       (const bf16_t*)y2, mul, add, mod_bstride, rows_per_batch, one, (bf16_t*)out, ldo, pfs, sat, sat_tag)
         if (ymode == 0) F5_LN_W(0);
         else if (ymode == 1) F5_LN_W(1);
         else if (ymode == 2) F5_LN_W(2);
@@ -315,7 +326,7 @@ int launch_layernorm_add2(int precision_out, float* x, int ldx, int rows, int di
                           const float* mul, const float* add, int mod_bstride, int rows_per_batch, int add_one, void* out, int ldo,
                           hipStream_t stream) {
     return launch_layernorm_res(precision_out, x, 0, x, 0, ldx, rows, dim, y, ldy, y2, ymode, mul, add, mod_bstride, rows_per_batch, add_one, out, ldo,
-                                stream, nullptr, nullptr);
+                                stream, nullptr, nullptr, 0);
 }
 
 int launch_layernorm_add(int precision_out, float* x, int ldx, int rows, int dim, const void* y, int ldy, const float* mul, const float* add,

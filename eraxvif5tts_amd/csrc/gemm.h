@@ -49,6 +49,7 @@ struct GemmParams {
     int conv_cg, conv_win;
     int tile_group;  // tuned kernel: token tiles per L2 patch (set by the launcher)
     int lean_epi;    // tuned kernel: whole tiles take the lean epilogue (set by the launcher; 0 = always the generic one)
+    unsigned long long* clk;  // diagnostic (f5_debug_gemm_clock): [workgroups][4] = (s_memtime, s_memrealtime) at workgroup start and end, or null
 };
 
 // kernel_kind: 0 = reference tile kernel (any shape), 1 = tuned 256x256 LDS-DMA bf16 kernel

@@ -39,6 +39,22 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    if (p.clk) {  // diagnostic: the clock the chip holds under this kernel = d(s_memtime) / d(s_memrealtime) x 100 MHz
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            p.clk[(size_t)blockIdx.x * 4 + 0] = t0;
+            p.clk[(size_t)blockIdx.x * 4 + 1] = r0;
+        }
+    }
+    auto clk_end = [&]() {
+        if (p.clk) {
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+            if (tid == 0) {
+                p.clk[(size_t)blockIdx.x * 4 + 2] = t1;
+                p.clk[(size_t)blockIdx.x * 4 + 3] = r1;
+            }
+        }
+    };
 
     // XCD-aware bijective remap (blocks b and b+8 share an XCD): give each XCD a contiguous band of tiles.
     // Inside an XCD band, walk groups of `gm` token tiles x all feature tiles with the token tile fastest: the ~32 tiles an
@@ -596,6 +612,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
                 epilogue();
             }
         }
+        clk_end();
         return;
     }
     constexpr int D = NSTAGE - 1;  // K-steps issued ahead of the one being consumed
@@ -646,8 +663,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
     }
 
     epilogue();
+    clk_end();
 }
 
+unsigned long long* g_gemm_clk_buf = nullptr;  // diagnostic (f5_debug_gemm_clock)
 int g_gemm_variant = 1;  // tuning knob (f5_tuning_set("gemm_variant", v)): 0 = plain ring everywhere, 1 = staggered wave groups (+ persistent grid)
 int g_gemm_group = 0;    // tuning knob ("gemm_group"): token tiles per L2 patch (0 = by shape, 1 = feature-tile-fastest order)
 int g_gemm_persist_grid = 0;  // tuning knob ("gemm_persist_grid"): workgroups of the persistent kernel (0 = one per CU of the device)
@@ -670,6 +689,7 @@ template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmPa
     // L2 patch height: 8 token tiles per XCD patch; 16 for the 8-feature-tile (N = 2048) projection (FF1 985 -> 1 020 TFLOP/s)
     p.tile_group = g_gemm_group > 0 ? g_gemm_group : (cdiv(p.N, BN) == 8 ? 16 : 8);
     p.lean_epi = g_gemm_lean;
+    p.clk = g_gemm_clk_buf;
     const int tiles_m = cdiv(p.M, 256), tiles_n = cdiv(p.N, BN);
     const int nblocks = tiles_m * tiles_n;
     dim3 grid(nblocks), block(512);

@@ -31,7 +31,8 @@ int launch_f32_to_f16(const float* src, void* dst, size_t n, hipStream_t stream,
 // residual stream read from xin (fp32, or fp16 when xin_f16) and, ymode 1 / 3, written to xout (fp32 / fp16): elementwise.hip
 int launch_layernorm_res(int precision_out, const void* xin, int xin_f16, void* xout, int xout_f16, int ldx, int rows, int dim, const void* y, int ldy,
                          const void* y2, int ymode, const float* mul, const float* add, int mod_bstride, int rows_per_batch, int add_one, void* out,
-                         int ldo, hipStream_t stream, const PrefetchSet* prefetch = nullptr, unsigned* sat = nullptr /* range guard of the fp16 stream */);
+                         int ldo, hipStream_t stream, const PrefetchSet* prefetch = nullptr, unsigned* sat = nullptr /* range guard of the fp16 stream */,
+                         int sat_tag = 0 /* diagnostics: pass kind | DiT block << 4 */);
 // depthwise Conv1d(k=7, pad=3) along the sequence (+bias) then LayerNorm(eps 1e-6, affine) -> activation dtype
 // x f32 [B*N, C]; wt f32 [7][C] (tap-major); out [B*N, C]
 int launch_dwconv7_ln(int precision_out, const float* x, int B, int N, int C, const float* wt, const float* cbias, const float* ln_w,

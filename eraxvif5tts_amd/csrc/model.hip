@@ -12,6 +12,8 @@
 //   * CFG runs cond and uncond branches as ONE 2B batch through every kernel;
 //   * the whole loop (precompute + steps x evaluation) is captured into one hipGraph per shape bucket.
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "gemm.h"
@@ -80,10 +82,14 @@ struct f5_plan_s {
     // the stream reaches fp16's largest finite value or is NaN; f5_sample reads it after the loop (the call's one synchronisation) and
     // repeats the loop with fp32 residual storage, which this plan then keeps (`res_f16` = 0).
     unsigned* sat_flag = nullptr;
+    unsigned* sat_base = nullptr;
     unsigned* sat_host = nullptr;  // pinned
     int res_f16 = -1;              // plan option "residual_f16": -1 = the process-wide knob, 0 = fp32 storage, 1 = fp16 storage
     int sat_check = 1;             // plan option "residual_guard": 0 = never read the flag (f5_sample stays fully asynchronous)
     int fallbacks = 0;             // calls repeated with fp32 storage so far (f5_plan_get_option "residual_fallbacks")
+    unsigned sat_amax_bits = 0;    // what the last event saw: largest finite |element| (float bits) and whether a NaN was read
+    bool sat_nan = false;
+    unsigned sat_pass = 0, sat_blocks = 0, sat_row = 0;  // which passes / DiT blocks raised it, smallest offending token row
     std::map<std::string, float*> taps;
     std::vector<float> mod_tv;  // evaluation times the AdaLN rows in `mod` were computed for (empty = stale); see f5_sample
     hipStream_t mod_stream = nullptr;  // ... and the stream they were computed on (a call on another stream recomputes them)
@@ -443,8 +449,9 @@ extern "C" int f5_plan_create(f5_model_t m, int max_batch, int max_seq, int max_
             }
         if ((rc = f5_upload_f32(A, rope.data(), rope.size(), &p->rope))) break;
         p->rope_n = max_seq;
-        if ((rc = A.alloc_t(&p->sat_flag, 4))) break;
-        if (hipHostMalloc((void**)&p->sat_host, 16, hipHostMallocDefault) != hipSuccess) {
+        if ((rc = A.alloc_t(&p->sat_base, 1024))) break;  // the 8 flag words sit in the middle of a 4 KiB block of their own
+        p->sat_flag = p->sat_base + 512;
+        if (hipHostMalloc((void**)&p->sat_host, 32, hipHostMallocDefault) != hipSuccess) {
             rc = f5_fail(F5_ENOMEM, "hipHostMalloc failed");
             break;
         }
@@ -509,6 +516,16 @@ extern "C" int f5_plan_get_option(f5_plan_t p, const char* key, int* value) {
         *value = p->sat_check;
     else if (strcmp(key, "residual_fallbacks") == 0)
         *value = p->fallbacks;
+    else if (strcmp(key, "residual_guard_amax_bits") == 0)  // diagnostic: float bits of the largest finite |element| the last event saw
+        *value = (int)p->sat_amax_bits;
+    else if (strcmp(key, "residual_guard_nan") == 0)
+        *value = p->sat_nan ? 1 : 0;
+    else if (strcmp(key, "residual_guard_pass") == 0)
+        *value = (int)p->sat_pass;
+    else if (strcmp(key, "residual_guard_blocks") == 0)
+        *value = (int)p->sat_blocks;
+    else if (strcmp(key, "residual_guard_row") == 0)
+        *value = (int)p->sat_row;
     else
         return f5_fail(F5_EINVAL, "unknown option '%s'", key);
     return 0;
@@ -575,6 +592,8 @@ int g_w_prefetch = 16384;  // tuning knob ("w_prefetch"): LayerNorm passes prefe
                             // (0 = never).  M = 8192: +2.3 %, M = 2048: +2.9 % mel-frames/s; M = 65536: no effect (each weight line serves 256 token tiles there)
 int g_res_f16 = 1;   // tuning knob ("residual_f16"): bf16 production mode keeps the residual stream in fp16 from the first block on (0 = fp32)
 int g_ln_defer = 1;  // tuning knob ("ln_defer"): write the residual stream once per DiT block (0 = after every LayerNorm pass)
+int g_sync_evals = 0;  // diagnostic knob ("sync_evals"): an eager sample() synchronises the stream after every network evaluation, which bounds the
+                       // number of dispatches in flight (profiles/r3_rocprof_pmc_sigsegv.md: rocprofv3 --pmc died under ~5 400 queued dispatches)
 
 // fp16 residual storage for this plan's evaluations (bf16 mode without stage taps; the plan option overrides the process-wide knob)
 static bool plan_res_f16(const f5_plan_s* p) {
@@ -722,7 +741,7 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
                         {(unsigned)(D * ff * wes), (unsigned)(3 * inner * D * wes), 0u, 0u}};
         F5_TRY(timed(p, F5_SITE_LN1, st, [&] {
             return launch_layernorm_res(P, xin, in16, xout, r16, D, rows, D, p->yT, D, nullptr, defer ? 2 : 1, ml + D, ml, mod_bstride, N, 1, p->hT, D, st,
-                                        wpf ? &pf1 : nullptr, sat);
+                                        wpf ? &pf1 : nullptr, sat, 1 | (l << 4));
         }));
         if (l == 0) F5_TRY(tap_f32(p, "input_embed", p->xres, D, rows, D, st));
         if (l > 0) F5_TRY(tap_f32(p, "blk" + std::to_string(l - 1) + ".out", p->xres, D, rows, D, st));
@@ -774,7 +793,7 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         // x += y; n2 = LN(x) * (1 + scale_mlp) + shift_mlp
         F5_TRY(timed(p, F5_SITE_LN2, st, [&] {
             return launch_layernorm_res(P, xin, in16, xout, r16, D, rows, D, p->yT, D, defer ? p->yA : nullptr, defer ? 3 : 1, ml + 4 * D, ml + 3 * D,
-                                        mod_bstride, N, 1, p->hT, D, st, wpf ? &pf2 : nullptr, sat);
+                                        mod_bstride, N, 1, p->hT, D, st, wpf ? &pf2 : nullptr, sat, 2 | (l << 4));
         }));
         g = gp_zero();
         g.A = p->hT; g.lda = D; g.W = b.w_ff1; g.ldw = D; g.M = rows; g.N = ff; g.K = D;
@@ -789,7 +808,7 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
     const float* mf = modp + (size_t)c.depth * 6 * D;  // final AdaLN: (scale, shift) (modules.py:333)
     // (no stage tap: the stream itself is not needed any more, so the last add is not written back)
     F5_TRY(launch_layernorm_res(P, r16 ? p->xres16 : (const void*)p->xres, r16, r16 ? p->xres16 : (void*)p->xres, r16, D, rows, D, p->yT, D, nullptr,
-                                defer ? 2 : 1, mf, mf + D, mod_bstride, N, 1, p->hT, D, st, nullptr, sat));
+                                defer ? 2 : 1, mf, mf + D, mod_bstride, N, 1, p->hT, D, st, nullptr, sat, 3));
     F5_TRY(tap_f32(p, "blk" + std::to_string(c.depth - 1) + ".out", p->xres, D, rows, D, st));
     F5_TRY(tap_t(p, "final_norm", p->hT, D, rows, D, st));
     g = gp_zero();
@@ -838,7 +857,11 @@ static int sample_body(f5_plan_s* p, const SampleArgs& a, hipStream_t st) {
     const int B = a.B, N = a.N, mel = c.mel_dim, bn = B * N;
     const int nev = a.method == F5_ODE_MIDPOINT ? 2 * a.steps : a.steps;
     const size_t state = (size_t)bn * mel;
-    F5_HIP(hipMemsetAsync(p->sat_flag, 0, 4, st));  // range guard of the fp16 residual stream: a node of the graph, so every replay starts clean
+    // range guard of the fp16 residual stream: cleared by a KERNEL node of the graph, so every replay starts clean.  (Not hipMemsetAsync: on
+    // ROCm 7.2 the 32-byte memset node captured here cleared the words on the first launch of the instantiated graph and filled them with
+    // two stale host pointers on every replay -- gpurun_out/r3g: [512..519] = {0xf5dffab8, 0x78fe, 0xea66b000, 0x7909} x 2 -- which read as
+    // a raised flag and sent the second sample() of every process through the fp32 fallback.)
+    F5_TRY(launch_fill_f32(reinterpret_cast<float*>(p->sat_flag), 8, 0.0f, st));
     // (the AdaLN modulation rows of all evaluation times are already in p->mod: f5_sample keeps them across calls)
     // text embeddings are constants of the whole sample() (the reference caches them per branch, dit.py:202-210)
     F5_TRY(compute_text_embed(p, p->text_in, a.nt, B, N, 0, p->te[0], st));
@@ -856,7 +879,10 @@ static int sample_body(f5_plan_s* p, const SampleArgs& a, hipStream_t st) {
         p->rowbits_src = mask;
     }
     const int nb = a.cfg_on ? 2 * B : B;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (g_sync_evals) (void)hipStreamIsCapturing(st, &capturing);
     for (int s = 0; s < a.steps; ++s) {
+        if (g_sync_evals && capturing == hipStreamCaptureStatusNone && s > 0) F5_HIP(hipStreamSynchronize(st));
         float* xs = p->traj + (size_t)s * state;
         float* xn = p->traj + (size_t)(s + 1) * state;
         const float* vu = a.cfg_on ? p->vout + (size_t)bn * MELP : nullptr;
@@ -981,9 +1007,28 @@ extern "C" int f5_sample(f5_plan_t p, int B, int N, const float* cond, const int
         // The stream was stored as saturating fp16: one 4-byte read of the flag the LayerNorm passes raise (the call's only synchronisation;
         // plan option "residual_guard" = 0 removes it).  A large-activation checkpoint must not clip silently: the loop is repeated with
         // fp32 residual storage -- y0 is still traj[0], every other input is staged -- and the plan keeps fp32 storage from now on.
-        F5_HIP(hipMemcpyAsync(p->sat_host, p->sat_flag, 4, hipMemcpyDeviceToHost, st));
+        F5_HIP(hipMemcpyAsync(p->sat_host, p->sat_flag, 32, hipMemcpyDeviceToHost, st));
         F5_HIP(hipStreamSynchronize(st));
+        if (getenv("F5HIP_DEBUG_GUARD")) {
+            static unsigned dump[1024];
+            (void)hipMemcpy(dump, p->sat_base, sizeof(dump), hipMemcpyDeviceToHost);
+            int nz = 0;
+            for (int i = 0; i < 1024; ++i)
+                if (dump[i]) ++nz;
+            fprintf(stderr, "[guard] flag block %p: %d non-zero words of 1024;", (void*)p->sat_base, nz);
+            for (int i = 0, shown = 0; i < 1024 && shown < 24; ++i)
+                if (dump[i]) {
+                    fprintf(stderr, " [%d]=0x%x", i, dump[i]);
+                    ++shown;
+                }
+            fprintf(stderr, "\n");
+        }
         if (*p->sat_host != 0u) {
+            p->sat_amax_bits = p->sat_host[1];
+            p->sat_nan = p->sat_host[2] != 0u;
+            p->sat_pass = p->sat_host[3];
+            p->sat_blocks = p->sat_host[4];
+            p->sat_row = 0x7fffffffu - p->sat_host[5];
             p->res_f16 = 0;
             ++p->fallbacks;
             drop_graphs();  // they baked the fp16 kernels

@@ -351,13 +351,40 @@ extern "C" int f5_bench_mfma_rate(int random_operands, float* tflops, f5_stream_
     return sync_and_release(a, st, rc);
 }
 
+extern int g_sync_evals, g_attn_persist, g_attn_stagger;
 extern int g_gemm_variant, g_gemm_group, g_gemm_persist_grid, g_gemm_persist, g_gemm_lean, g_ln_defer, g_ln_wide, g_w_prefetch, g_res_f16, g_conv31, g_attn_variant, g_vocos_fft;
 int g_tuning_epoch = 0;
+extern unsigned long long* g_attn_stamp_buf;
+extern unsigned long long* g_gemm_clk_buf;
+// diagnostic: while dev_buf (u64 [workgroups * 4]) is non-null the tuned GEMM writes (s_memtime, s_memrealtime) at workgroup start and end
+extern "C" int f5_debug_gemm_clock(void* dev_buf) {
+    g_gemm_clk_buf = reinterpret_cast<unsigned long long*>(dev_buf);
+    return 0;
+}
+// diagnostic: the persistent attention kernel writes shader-clock stamps (wave 0 of every workgroup, first 8 items, 8 stamps each) into
+// `dev_buf` (u64 [workgroups * 64]) while it is non-null
+extern "C" int f5_debug_attn_stamps(void* dev_buf) {
+    g_attn_stamp_buf = reinterpret_cast<unsigned long long*>(dev_buf);
+    return 0;
+}
+
 extern "C" int f5_tuning_set(const char* key, int value) {
     if (!key) return f5_fail(F5_EINVAL, "null key");
     ++g_tuning_epoch;  // hipGraphs captured by plans under the previous knob values are dropped at their next use (model.hip)
     if (strcmp(key, "gemm_variant") == 0) {
         g_gemm_variant = value;
+        return 0;
+    }
+    if (strcmp(key, "attn_stagger") == 0) {
+        g_attn_stagger = value;
+        return 0;
+    }
+    if (strcmp(key, "attn_persist") == 0) {
+        g_attn_persist = value != 0;
+        return 0;
+    }
+    if (strcmp(key, "sync_evals") == 0) {
+        g_sync_evals = value != 0;
         return 0;
     }
     if (strcmp(key, "w_prefetch") == 0) {

@@ -265,9 +265,20 @@ class DiT(nn.Module):
             _lib.check(lib.f5_plan_get_option(plan, b"residual_fallbacks", C.byref(n)), "plan_get_option")
             if n.value > self._fallbacks_seen.get(plan.value, 0):
                 self._fallbacks_seen[plan.value] = n.value
+                import struct
                 import warnings
-                warnings.warn("libf5hip: the residual stream left the fp16 range (|x| >= 65504 or NaN); sample() was repeated with fp32 residual "
-                              "storage, which this plan keeps from now on", RuntimeWarning, stacklevel=2)
+                bits, nan = C.c_int(0), C.c_int(0)
+                _lib.check(lib.f5_plan_get_option(plan, b"residual_guard_amax_bits", C.byref(bits)), "plan_get_option")
+                _lib.check(lib.f5_plan_get_option(plan, b"residual_guard_nan", C.byref(nan)), "plan_get_option")
+                amax = struct.unpack("f", struct.pack("I", bits.value & 0xffffffff))[0]
+                diag = {}
+                for k in ("pass", "blocks", "row"):
+                    v = C.c_int(0)
+                    _lib.check(lib.f5_plan_get_option(plan, f"residual_guard_{k}".encode(), C.byref(v)), "plan_get_option")
+                    diag[k] = v.value & 0xffffffff
+                warnings.warn(f"libf5hip: the residual stream left the fp16 range (largest |element| seen {amax:.6g}, NaN seen: {bool(nan.value)}, "
+                              f"passes 0x{diag['pass']:x}, blocks 0x{diag['blocks']:x}, first row {diag['row']}); "
+                              "sample() was repeated with fp32 residual storage, which this plan keeps from now on", RuntimeWarning, stacklevel=2)
         return out, traj
 
     def residual_fallbacks(self):

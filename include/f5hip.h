@@ -212,6 +212,12 @@ F5_API int f5_bench_attention(int kernel, int B, int N, int H, int iters, float*
 /* Sustained rate of a register-resident v_mfma_f32_16x16x32_bf16 stream on every CU (no memory traffic): random_operands = 0 zeros
  * (clock-limited), 1 pseudo-random bf16 values (power-limited: what a dense bf16 GEMM can approach on this device). */
 F5_API int f5_bench_mfma_rate(int random_operands, float* tflops, f5_stream_t stream);
+/* diagnostic build of the persistent attention kernel: while dev_buf (dev u64 [workgroups * 64]) is non-NULL every launch writes shader-clock
+ * stamps of wave 0 (first 8 items of each workgroup: item start, Q prefetch issued, key tiles 0 / 1 / 2 / last done, epilogue done) */
+F5_API int f5_debug_attn_stamps(void* dev_buf);
+/* the clock the chip holds under the tuned GEMM: while dev_buf (dev u64 [workgroups * 4]) is non-NULL every workgroup writes (s_memtime,
+ * s_memrealtime) at its start and end; clock = d(s_memtime) / d(s_memrealtime) x 100 MHz */
+F5_API int f5_debug_gemm_clock(void* dev_buf);
 /* process-wide kernel tuning knobs for A/B measurements ("gemm_variant": main-loop schedule of the tuned GEMM) */
 F5_API int f5_tuning_set(const char* key, int value);
 

@@ -256,6 +256,31 @@ def test_attention_tuned_kernel_long_sequences(variant, N, masked):
     assert (out[valid] - ref[valid]).abs().max() < 0.05
 
 
+@pytest.mark.parametrize("B,N,H", [(1, 1024, 2), (3, 512, 8), (2, 768, 1), (20, 768, 16), (1, 4096, 2), (9, 256, 16)])
+def test_attention_persistent_grid(B, N, H):
+    """attn_persist_kernel (attn_variant 6: two workgroups per CU walk the (batch, head, 256-query block) items; the K/V ring, the Q prefetch by
+    LDS-DMA and the staged output stores run on across item boundaries) against the fp64 softmax (modules.py:483-497): fewer items than
+    workgroups, exactly one each, an uneven one-or-two split (20 x 16 heads x 3 blocks = 960 items on 512 workgroups), a (batch x head) count
+    that is not a multiple of the 8 XCDs, the shortest eligible sequence (256 = 4 key tiles), N = 4096; and bit-identical to the one-item-per-
+    workgroup kernel (same arithmetic, different schedule)."""
+    import gpu_helpers as G
+    from eraxvif5tts_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(N + H + B)
+    qkv = G.bf16_round(torch.randn(B, N, 3, H, 64, generator=g) * 1.5)
+    ref = _attn_ref(qkv, None)
+    outs = {}
+    for variant in (6, 2):
+        _lib.check(lib.f5_tuning_set(b"attn_variant", variant))
+        try:
+            outs[variant] = G.op_attention(P_BF16, 1, qkv, None)
+        finally:
+            _lib.check(lib.f5_tuning_set(b"attn_variant", 0))
+    assert torch.isfinite(outs[6]).all()
+    assert rel_l2(outs[6], ref) < 6e-3 and (outs[6] - ref).abs().max() < 0.05
+    assert torch.equal(outs[6], outs[2])
+
+
 @pytest.mark.parametrize("masked", [False, True], ids=["unmasked", "ragged_lens"])
 def test_attention_beyond_the_validity_table(masked):
     """N = 8320 = 130 key tiles: past the 128-tile table of key validity bits the wide kernel keeps in LDS.  Unmasked (whole tiles) it still
@@ -277,7 +302,7 @@ def test_attention_beyond_the_validity_table(masked):
     assert rel_l2(out[valid], ref[valid]) < 6e-3
 
 
-@pytest.mark.parametrize("variant", [0, 2, 5])
+@pytest.mark.parametrize("variant", [0, 2, 5, 6])
 def test_attention_long_sequence_spiked_scores(variant):
     """online-softmax rescale path of every schedule at N = 4096: the running max jumps late (key 3900) and in the first tile."""
     import gpu_helpers as G
@@ -297,7 +322,7 @@ def test_attention_long_sequence_spiked_scores(variant):
     assert rel_l2(out, ref) < 6e-3
 
 
-@pytest.mark.parametrize("variant", [2, 5])
+@pytest.mark.parametrize("variant", [2, 5, 6])
 def test_attention_deferred_rescale_thresholds(variant):
     """Exponent-reference handling of both schedules (pipelined kernel: the reference moves only when a row maximum outgrew it by more
     than 2^16; 64-queries-per-wave kernel: no maximum unless a row sum leaves the guarded range): score jumps just below and far above

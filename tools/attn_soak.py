@@ -14,9 +14,9 @@ import gpu_helpers as G  # noqa: E402
 lib = _lib.load()
 _lib.require_gpu()
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-for variant in (2, 5):
+for variant in (2, 5, 6):
     for (B, N, H, masked) in ((8, 1024, 16, False), (6, 1000, 16, True), (2, 4096, 16, False), (3, 4033, 8, True), (5, 333, 4, True), (64, 256, 16, False),
-                              (1, 1000, 16, False), (2, 4033, 16, False)):  # ragged N without a mask array: the MASKED build with mask == nullptr (single-utterance serving)
+                              (1, 1000, 16, False), (2, 4033, 16, False), (20, 768, 16, False), (64, 1024, 16, False)):  # ragged N without a mask array: the MASKED build with mask == nullptr (single-utterance serving)
         g = torch.Generator().manual_seed(N + H)
         qkv = G.bf16_round(torch.randn(B, N, 3, H, 64, generator=g) * 1.5)
         mask = None
