@@ -52,6 +52,7 @@ _PROTOS = {
     "f5_plan_destroy": (_I, [_P]),
     "f5_plan_workspace_bytes": (C.c_int64, [_P]),
     "f5_sample": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _F, _I, _P, _P, _I, _P]),
+    "f5_sample_finish": (_I, [_P, _P]),
     "f5_text_embed": (_I, [_P, _I, _I, _P, _I, _I, _P, _P]),
     "f5_dit_forward": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "f5_plan_timing_begin": (_I, [_P, _I]),

@@ -61,6 +61,19 @@ struct GraphEntry {
     hipGraphExec_t exec = nullptr;
 };
 
+struct SampleArgs {
+    int B, N, nt, steps, method, cfg_on, mask_on;
+    float cfg;
+};
+// a sample() whose range-guard check was deferred (plan option "residual_guard" = 2): what f5_sample_finish needs to repeat it
+struct PendingSample {
+    bool valid = false;
+    SampleArgs a{};
+    int use_graph = 0;
+    float* out = nullptr;
+    float* trajectory = nullptr;
+};
+
 struct f5_plan_s {
     f5_model_s* m = nullptr;
     int maxB = 0, maxN = 0, maxE = 0;
@@ -86,6 +99,7 @@ struct f5_plan_s {
     unsigned* sat_host = nullptr;  // pinned
     int res_f16 = -1;              // plan option "residual_f16": -1 = the process-wide knob, 0 = fp32 storage, 1 = fp16 storage
     int sat_check = 1;             // plan option "residual_guard": 0 = never read the flag (f5_sample stays fully asynchronous)
+    PendingSample pending;
     int fallbacks = 0;             // calls repeated with fp32 storage so far (f5_plan_get_option "residual_fallbacks")
     unsigned sat_amax_bits = 0;    // what the last event saw: largest finite |element| (float bits) and whether a NaN was read
     bool sat_nan = false;
@@ -484,21 +498,29 @@ extern "C" int64_t f5_plan_workspace_bytes(f5_plan_t p) { return p ? (int64_t)p-
 
 extern "C" int f5_plan_set_option(f5_plan_t p, const char* key, int value) {
     if (!p || !key) return f5_fail(F5_EINVAL, "null argument");
-    if (strcmp(key, "gemm_kernel") == 0)
+    bool rebake = false;  // captured graphs baked the previous kernel choice
+    if (strcmp(key, "gemm_kernel") == 0) {
+        rebake = p->gemm_kernel != value;
         p->gemm_kernel = value;
-    else if (strcmp(key, "attn_kernel") == 0)
+    } else if (strcmp(key, "attn_kernel") == 0) {
+        rebake = p->attn_kernel != value;
         p->attn_kernel = value;
-    else if (strcmp(key, "residual_f16") == 0)
-        p->res_f16 = value < 0 ? -1 : (value != 0);
-    else if (strcmp(key, "residual_guard") == 0)
-        p->sat_check = value != 0;
-    else
+    } else if (strcmp(key, "residual_f16") == 0) {
+        const int v = value < 0 ? -1 : (value != 0);
+        rebake = p->res_f16 != v;
+        p->res_f16 = v;
+    } else if (strcmp(key, "residual_guard") == 0) {
+        p->sat_check = value < 0 ? 0 : (value > 2 ? 2 : value);  // 0 off, 1 checked inside f5_sample, 2 deferred to f5_sample_finish (host-side only)
+    } else {
         return f5_fail(F5_EINVAL, "unknown option '%s'", key);
-    for (auto& g : p->graphs) {  // captured graphs baked the previous choice
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-        if (g.graph) (void)hipGraphDestroy(g.graph);
     }
-    p->graphs.clear();
+    if (rebake) {
+        for (auto& g : p->graphs) {
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            if (g.graph) (void)hipGraphDestroy(g.graph);
+        }
+        p->graphs.clear();
+    }
     return 0;
 }
 
@@ -845,10 +867,6 @@ extern "C" int f5_dit_forward(f5_plan_t p, int B, int N, const float* x, const f
 }
 
 // ----------------------------------------------------------------------------- public: sample
-struct SampleArgs {
-    int B, N, nt, steps, method, cfg_on, mask_on;
-    float cfg;
-};
 
 // everything between the staged inputs and the final state traj[steps]; capturable (no syncs, no allocations)
 static int sample_body(f5_plan_s* p, const SampleArgs& a, hipStream_t st) {
@@ -896,6 +914,90 @@ static int sample_body(f5_plan_s* p, const SampleArgs& a, hipStream_t st) {
             F5_TRY(launch_cfg_step(xs, p->vout, vu, MELP, bn, mel, a.cfg, p->coefs + 2 * s + 1, xn, nullptr, st));
         }
     }
+    return 0;
+}
+
+static void drop_graphs(f5_plan_s* p) {
+    for (auto& g : p->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    p->graphs.clear();
+}
+
+// the ODE loop of one sample() on the staged inputs: replay of the hipGraph captured for this exact problem, or eager launches
+static int run_sample_loop(f5_plan_s* p, const SampleArgs& a, int use_graph, hipStream_t st) {
+    if (use_graph && p->taps.empty() && !p->timing) {
+        GraphEntry* ge = nullptr;
+        for (size_t i = 0; i < p->graphs.size();) {  // a tuning knob changed since the capture: the graph baked the old kernel choice
+            if (p->graphs[i].epoch != g_tuning_epoch) {
+                (void)hipGraphExecDestroy(p->graphs[i].exec);
+                (void)hipGraphDestroy(p->graphs[i].graph);
+                p->graphs.erase(p->graphs.begin() + i);
+            } else {
+                ++i;
+            }
+        }
+        for (auto& g : p->graphs)
+            if (g.B == a.B && g.N == a.N && g.nt == a.nt && g.steps == a.steps && g.method == a.method && g.cfg_on == a.cfg_on &&
+                g.mask_on == a.mask_on && g.cfg == a.cfg)
+                ge = &g;
+        if (!ge) {
+            GraphEntry g{a.B, a.N, a.nt, a.steps, a.method, a.cfg_on, a.mask_on, a.cfg, g_tuning_epoch};
+            if (!p->cap_stream) F5_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
+            F5_HIP(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeRelaxed));
+            int rc = sample_body(p, a, p->cap_stream);
+            hipError_t e = hipStreamEndCapture(p->cap_stream, &g.graph);
+            if (rc != 0) {
+                if (g.graph) (void)hipGraphDestroy(g.graph);
+                return rc;
+            }
+            if (e != hipSuccess) return f5_fail(F5_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+            e = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
+            if (e != hipSuccess) {
+                (void)hipGraphDestroy(g.graph);
+                return f5_fail(F5_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+            }
+            if (p->graphs.size() >= 8) {  // small LRU-less cache: drop the oldest bucket
+                (void)hipGraphExecDestroy(p->graphs[0].exec);
+                (void)hipGraphDestroy(p->graphs[0].graph);
+                p->graphs.erase(p->graphs.begin());
+            }
+            p->graphs.push_back(g);
+            ge = &p->graphs.back();
+        }
+        F5_HIP(hipGraphLaunch(ge->exec, st));
+    } else {
+        F5_TRY(sample_body(p, a, st));
+    }
+    return 0;
+}
+
+// The stream was stored as saturating fp16: one small read of the flag words the LayerNorm passes raise (a stream synchronisation).  A
+// large-activation checkpoint must not clip silently: the loop is repeated with fp32 residual storage -- y0 is still traj[0], every other
+// input is staged -- and the plan keeps fp32 storage from now on.
+static int guard_check_and_fallback(f5_plan_s* p, const SampleArgs& a, int use_graph, hipStream_t st) {
+    F5_HIP(hipMemcpyAsync(p->sat_host, p->sat_flag, 32, hipMemcpyDeviceToHost, st));
+    F5_HIP(hipStreamSynchronize(st));
+    if (*p->sat_host != 0u) {
+        p->sat_amax_bits = p->sat_host[1];
+        p->sat_nan = p->sat_host[2] != 0u;
+        p->sat_pass = p->sat_host[3];
+        p->sat_blocks = p->sat_host[4];
+        p->sat_row = 0x7fffffffu - p->sat_host[5];
+        p->res_f16 = 0;
+        ++p->fallbacks;
+        drop_graphs(p);  // they baked the fp16 kernels
+        F5_TRY(run_sample_loop(p, a, use_graph, st));
+    }
+    return 0;
+}
+
+static int finish_outputs(f5_plan_s* p, const SampleArgs& a, float* out, float* trajectory, hipStream_t st) {
+    const int mel = p->m->cfg.mel_dim;
+    const size_t state = (size_t)a.B * a.N * mel;
+    F5_TRY(launch_final_where(p->cond_in, p->traj + (size_t)a.steps * state, p->lens_in, a.B, a.N, mel, out, st));
+    if (trajectory) F5_HIP(hipMemcpyAsync(trajectory, p->traj, (size_t)(a.steps + 1) * state * sizeof(float), hipMemcpyDeviceToDevice, st));
     return 0;
 }
 
@@ -948,94 +1050,27 @@ extern "C" int f5_sample(f5_plan_t p, int B, int N, const float* cond, const int
     if (durations) F5_HIP(hipMemcpyAsync(p->dur_in, durations, B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
 
     SampleArgs a{B, N, nt_eff, steps, ode_method, cfg_strength >= 1e-5f ? 1 : 0, durations ? 1 : 0, cfg_strength};  // cfm.py:167
-    auto drop_graphs = [&]() {
-        for (auto& g : p->graphs) {
-            if (g.exec) (void)hipGraphExecDestroy(g.exec);
-            if (g.graph) (void)hipGraphDestroy(g.graph);
-        }
-        p->graphs.clear();
-    };
-    auto run_loop = [&]() -> int {
-        if (use_graph && p->taps.empty() && !p->timing) {
-            GraphEntry* ge = nullptr;
-            for (size_t i = 0; i < p->graphs.size();) {  // a tuning knob changed since the capture: the graph baked the old kernel choice
-                if (p->graphs[i].epoch != g_tuning_epoch) {
-                    (void)hipGraphExecDestroy(p->graphs[i].exec);
-                    (void)hipGraphDestroy(p->graphs[i].graph);
-                    p->graphs.erase(p->graphs.begin() + i);
-                } else {
-                    ++i;
-                }
-            }
-            for (auto& g : p->graphs)
-                if (g.B == B && g.N == N && g.nt == a.nt && g.steps == steps && g.method == ode_method && g.cfg_on == a.cfg_on &&
-                    g.mask_on == a.mask_on && g.cfg == a.cfg)
-                    ge = &g;
-            if (!ge) {
-                GraphEntry g{B, N, a.nt, steps, ode_method, a.cfg_on, a.mask_on, a.cfg, g_tuning_epoch};
-                if (!p->cap_stream) F5_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
-                F5_HIP(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeRelaxed));
-                int rc = sample_body(p, a, p->cap_stream);
-                hipError_t e = hipStreamEndCapture(p->cap_stream, &g.graph);
-                if (rc != 0) {
-                    if (g.graph) (void)hipGraphDestroy(g.graph);
-                    return rc;
-                }
-                if (e != hipSuccess) return f5_fail(F5_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
-                e = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
-                if (e != hipSuccess) {
-                    (void)hipGraphDestroy(g.graph);
-                    return f5_fail(F5_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
-                }
-                if (p->graphs.size() >= 8) {  // small LRU-less cache: drop the oldest bucket
-                    (void)hipGraphExecDestroy(p->graphs[0].exec);
-                    (void)hipGraphDestroy(p->graphs[0].graph);
-                    p->graphs.erase(p->graphs.begin());
-                }
-                p->graphs.push_back(g);
-                ge = &p->graphs.back();
-            }
-            F5_HIP(hipGraphLaunch(ge->exec, st));
-        } else {
-            F5_TRY(sample_body(p, a, st));
-        }
-        return 0;
-    };
     const bool guarded = plan_res_f16(p) && p->sat_check && !p->timing;
-    F5_TRY(run_loop());
-    if (guarded) {
-        // The stream was stored as saturating fp16: one 4-byte read of the flag the LayerNorm passes raise (the call's only synchronisation;
-        // plan option "residual_guard" = 0 removes it).  A large-activation checkpoint must not clip silently: the loop is repeated with
-        // fp32 residual storage -- y0 is still traj[0], every other input is staged -- and the plan keeps fp32 storage from now on.
-        F5_HIP(hipMemcpyAsync(p->sat_host, p->sat_flag, 32, hipMemcpyDeviceToHost, st));
-        F5_HIP(hipStreamSynchronize(st));
-        if (getenv("F5HIP_DEBUG_GUARD")) {
-            static unsigned dump[1024];
-            (void)hipMemcpy(dump, p->sat_base, sizeof(dump), hipMemcpyDeviceToHost);
-            int nz = 0;
-            for (int i = 0; i < 1024; ++i)
-                if (dump[i]) ++nz;
-            fprintf(stderr, "[guard] flag block %p: %d non-zero words of 1024;", (void*)p->sat_base, nz);
-            for (int i = 0, shown = 0; i < 1024 && shown < 24; ++i)
-                if (dump[i]) {
-                    fprintf(stderr, " [%d]=0x%x", i, dump[i]);
-                    ++shown;
-                }
-            fprintf(stderr, "\n");
-        }
-        if (*p->sat_host != 0u) {
-            p->sat_amax_bits = p->sat_host[1];
-            p->sat_nan = p->sat_host[2] != 0u;
-            p->sat_pass = p->sat_host[3];
-            p->sat_blocks = p->sat_host[4];
-            p->sat_row = 0x7fffffffu - p->sat_host[5];
-            p->res_f16 = 0;
-            ++p->fallbacks;
-            drop_graphs();  // they baked the fp16 kernels
-            F5_TRY(run_loop());
-        }
+    F5_TRY(run_sample_loop(p, a, use_graph, st));
+    p->pending = PendingSample{};
+    if (guarded && p->sat_check == 2) {
+        // deferred guard (plan option "residual_guard" = 2): nothing synchronises here, so several plans can be fed on several streams from
+        // one host thread; f5_sample_finish reads the flag later and repeats the loop if it must (the inputs stay staged in the plan)
+        p->pending = PendingSample{true, a, use_graph, out, trajectory};
+    } else if (guarded) {
+        F5_TRY(guard_check_and_fallback(p, a, use_graph, st));
     }
-    F5_TRY(launch_final_where(p->cond_in, p->traj + (size_t)steps * state, p->lens_in, B, N, mel, out, st));
-    if (trajectory) F5_HIP(hipMemcpyAsync(trajectory, p->traj, (size_t)(steps + 1) * state * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return finish_outputs(p, a, out, trajectory, st);
+}
+
+extern "C" int f5_sample_finish(f5_plan_t p, f5_stream_t stream) {
+    if (!p) return f5_fail(F5_EINVAL, "null plan");
+    if (!p->pending.valid) return 0;
+    const PendingSample ps = p->pending;
+    p->pending = PendingSample{};
+    hipStream_t st = (hipStream_t)stream;
+    const int before = p->fallbacks;
+    F5_TRY(guard_check_and_fallback(p, ps.a, ps.use_graph, st));
+    if (p->fallbacks != before) return finish_outputs(p, ps.a, ps.out, ps.trajectory, st);  // the loop ran again: write the outputs again
     return 0;
 }

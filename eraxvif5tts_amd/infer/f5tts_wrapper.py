@@ -101,6 +101,9 @@ class F5TTSWrapper:
         self.ref_audio_len = None
         self.target_rms = 0.1
         self.cross_fade_duration = 0.15
+        # text chunks of one generate() call sampled concurrently (HIP streams); 1 = one after the other as the reference does.  Not a
+        # constructor argument (the reference's signature is kept); set the attribute or F5HIP_CHUNK_STREAMS
+        self.chunk_streams = int(os.environ.get("F5HIP_CHUNK_STREAMS", "4"))
         self.nfe_step = 32
         self.cfg_strength = 2.0
         self.sway_sampling_coef = -1.0
@@ -178,7 +181,20 @@ class F5TTSWrapper:
         print("\n")
 
         generated_waves, spectrograms = [], []
-        for text_batch in text_batches:
+        # The text chunks of one call are independent (the reference samples them one after the other, :476-533).  Here up to `chunk_streams`
+        # of them are in flight at once, each on a HIP stream (and a libf5hip plan) of its own: a single-utterance sample() fills a fraction
+        # of the 256 CUs, so the streams overlap.  Every chunk runs exactly the launches of the serial path -- same shapes, same kernels --
+        # so its mel is bit-identical to the serial result; noise is drawn in chunk order either way.
+        transformer = getattr(self.model, "transformer", None)
+        n_streams = 1
+        if torch.cuda.is_available() and hasattr(transformer, "finish_pending"):
+            n_streams = max(1, min(len(text_batches), int(self.chunk_streams)))
+        main = torch.cuda.current_stream() if n_streams > 1 else None
+        streams = self._chunk_stream_pool(n_streams) if n_streams > 1 else []
+        for st in streams:
+            st.wait_stream(main)  # the preprocessed prompt was produced on the caller's stream
+        mels = []
+        for i, text_batch in enumerate(text_batches):
             local_speed = 0.3 if len(text_batch.encode("utf-8")) < 10 else speed
             final_text_list = convert_char_to_pinyin([self.ref_text + text_batch])
             if fix_duration is not None:
@@ -197,8 +213,21 @@ class F5TTSWrapper:
                 duration = self.ref_audio_len + int(self.ref_audio_len / ref_text_len * gen_text_len / local_speed)
                 print(f"Calculated duration based on text ratio: {duration} frames")
             with torch.inference_mode():
-                generated, _ = self.model.sample(cond=self.ref_audio_processed, text=final_text_list, duration=duration, steps=nfe_step,
-                                                 cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef, return_trajectory=False)
+                if n_streams > 1:
+                    with torch.cuda.stream(streams[i % n_streams]):
+                        generated, _ = self.model.sample(cond=self.ref_audio_processed, text=final_text_list, duration=duration, steps=nfe_step,
+                                                         cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef, return_trajectory=False,
+                                                         defer_guard=True)
+                else:
+                    generated, _ = self.model.sample(cond=self.ref_audio_processed, text=final_text_list, duration=duration, steps=nfe_step,
+                                                     cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef, return_trajectory=False)
+                mels.append(generated)
+        if n_streams > 1:
+            transformer.finish_pending()  # synchronises every chunk stream (and lets the library redo a chunk whose fp16 range guard fired)
+        with torch.inference_mode():
+            for generated in mels:
+                if n_streams > 1:
+                    generated.record_stream(main)
                 generated = generated.to(torch.float32)[:, self.ref_audio_len:, :].permute(0, 2, 1)
                 generated_wave = self.vocoder.decode(generated)
                 rms = torch.sqrt(torch.mean(torch.square(self.ref_audio_processed)))  # of the stored, already boosted prompt (:529-531)
@@ -224,6 +253,13 @@ class F5TTSWrapper:
         if return_spectrogram:
             return final_wave, self.target_sample_rate, combined_spectrogram
         return final_wave, self.target_sample_rate
+
+    def _chunk_stream_pool(self, n):
+        pool = getattr(self, "_chunk_streams_pool", None) or []
+        while len(pool) < n:
+            pool.append(torch.cuda.Stream())
+        self._chunk_streams_pool = pool
+        return pool[:n]
 
     def get_current_audio_length(self):
         if self.ref_audio_processed is None:

@@ -113,6 +113,7 @@ class DiT(nn.Module):
         self._plans = []
         self._seen_shapes = {}
         self._fallbacks_seen = {}
+        self._pending = {}  # plan handle -> stream of a sample() whose range-guard check was deferred (finish_pending)
         self.register_load_state_dict_post_hook(lambda module, _keys: module._drop_native())
 
     # ------------------------------------------------------------------ native handle management
@@ -121,6 +122,7 @@ class DiT(nn.Module):
         for _, h in self._plans:
             lib.f5_plan_destroy(h)
         self._plans = []
+        self._pending = {}
         if self._native is not None:
             lib.f5_model_destroy(self._native)
             self._native = None
@@ -168,18 +170,24 @@ class DiT(nn.Module):
         return h
 
     def plan(self, batch, seq, evals=1):
-        """Workspace for (batch, seq) problems; reused while it is large enough."""
+        """Workspace for (batch, seq) problems ON THE CURRENT STREAM; reused while it is large enough.  A plan's buffers are ordered only by the
+        stream its calls run on, so every stream gets plans of its own (F5TTSWrapper.generate samples its text chunks on several streams)."""
         self.native()  # (drops stale plans when a parameter changed in place)
-        for (b, n, e), h in self._plans:
-            if b >= batch and n >= seq and e >= evals:
+        stream = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0
+        for (st, b, n, e), h in self._plans:
+            if st == stream and b >= batch and n >= seq and e >= evals:
                 return h
         lib = _lib.load()
         seq_cap = min(4096, -(-seq // 64) * 64)
         h = C.c_void_p()
         _lib.check(lib.f5_plan_create(self.native(), batch, seq_cap, max(evals, 1), C.byref(h)), "plan_create")
-        while len(self._plans) >= 2:  # keep HBM use bounded: drop the oldest bucket
-            lib.f5_plan_destroy(self._plans.pop(0)[1])
-        self._plans.append(((batch, seq_cap, max(evals, 1)), h))
+        mine = [i for i, (k, _) in enumerate(self._plans) if k[0] == stream]
+        while len(mine) >= 2 or (len(self._plans) >= 12 and mine):  # keep HBM use bounded: at most two buckets per stream
+            key, old = self._plans.pop(mine.pop(0))
+            self._pending.pop(old.value, None)
+            lib.f5_plan_destroy(old)
+            mine = [i for i, (k, _) in enumerate(self._plans) if k[0] == stream]
+        self._plans.append(((stream, batch, seq_cap, max(evals, 1)), h))
         return h
 
     def set_kernels(self, gemm=None, attn=None):
@@ -232,7 +240,7 @@ class DiT(nn.Module):
 
     # ------------------------------------------------------------------ whole-loop entry used by CFM.sample
     def native_sample(self, cond, text, lens, durations, y0, tgrid, steps, cfg_strength, method="euler", use_mask=True,
-                      return_trajectory=False, use_graph=True):
+                      return_trajectory=False, use_graph=True, defer_guard=False):
         """cond/y0 f32 [B,N,mel] on the GPU, text int [B,nt] (-1 padded), lens/durations int [B], tgrid f32 [steps+1] (any device)."""
         lib = _lib.load()
         B, N = cond.shape[0], cond.shape[1]
@@ -255,9 +263,29 @@ class DiT(nn.Module):
         out = torch.empty_like(cond)
         traj = torch.empty(steps + 1, B, N, self.mel_dim, device=dev, dtype=torch.float32) if return_trajectory else None
         meth = {"euler": _lib.F5_ODE_EULER, "midpoint": _lib.F5_ODE_MIDPOINT}[method]
+        # defer_guard: f5_sample enqueues and returns without its one synchronisation (the fp16 range-guard read); finish_pending() does it
+        _lib.check(lib.f5_plan_set_option(plan, b"residual_guard", 2 if defer_guard else 1), "plan_set_option")
         _lib.check(lib.f5_sample(plan, B, N, _lib.ptr(cond), _lib.ptr(ids), ids.shape[1], _lib.ptr(lens32), _lib.ptr(dur32), _lib.ptr(y0),
                                  C.c_void_p(tg.data_ptr()), steps, float(cfg_strength), meth, _lib.ptr(out), _lib.ptr(traj),
                                  int(bool(use_graph)), _lib.stream_ptr()), "sample")
+        if defer_guard:
+            self._pending[plan.value] = (plan, torch.cuda.current_stream())
+            return out, traj
+        self._report_fallback(lib, plan)
+        return out, traj
+
+    def finish_pending(self):
+        """Complete every sample() issued with defer_guard=True: synchronise its stream, read the range-guard flag and let the library repeat
+        the loop with fp32 residual storage if it was raised (the outputs are rewritten in place).  Returns the number of calls finished."""
+        lib = _lib.load()
+        pending, self._pending = self._pending, {}
+        for plan, stream in pending.values():
+            with torch.cuda.stream(stream):
+                _lib.check(lib.f5_sample_finish(plan, C.c_void_p(stream.cuda_stream)), "sample_finish")
+            self._report_fallback(lib, plan)
+        return len(pending)
+
+    def _report_fallback(self, lib, plan):
         if self.precision == _lib.F5_PREC_BF16:
             # fp16 residual-stream range guard (include/f5hip.h, plan option "residual_guard"): the library repeated the loop with fp32
             # residual storage when an activation reached fp16's range, and keeps fp32 storage for this plan; say so once per event
@@ -278,8 +306,7 @@ class DiT(nn.Module):
                     diag[k] = v.value & 0xffffffff
                 warnings.warn(f"libf5hip: the residual stream left the fp16 range (largest |element| seen {amax:.6g}, NaN seen: {bool(nan.value)}, "
                               f"passes 0x{diag['pass']:x}, blocks 0x{diag['blocks']:x}, first row {diag['row']}); "
-                              "sample() was repeated with fp32 residual storage, which this plan keeps from now on", RuntimeWarning, stacklevel=2)
-        return out, traj
+                              "sample() was repeated with fp32 residual storage, which this plan keeps from now on", RuntimeWarning, stacklevel=3)
 
     def residual_fallbacks(self):
         """Number of sample() calls (over the live plans) that the library repeated with fp32 residual storage."""

@@ -42,10 +42,12 @@ class CFM(nn.Module):
     @torch.no_grad()
     def sample(self, cond, text, duration, *, lens=None, steps=32, cfg_strength=1.0, sway_sampling_coef=None, seed=None,
                max_duration=4096, vocoder=None, no_ref_audio=False, duplicate_test=False, t_inter=0.1, edit_mask=None,
-               y0=None, return_trajectory=True, use_graph="auto"):
+               y0=None, return_trajectory=True, use_graph="auto", defer_guard=False):
         """Same arguments and return value ``(out, trajectory)`` as the reference.  Extra keyword-only knobs:
         ``y0`` (explicit initial noise, zero-padded [b, N, mel]: parity tests), ``return_trajectory=False`` skips
-        materialising the [steps+1, b, N, mel] trajectory (returned as None), ``use_graph`` = True / False / "auto" (default: replay a hipGraph from the second call with the same shape on)."""
+        materialising the [steps+1, b, N, mel] trajectory (returned as None), ``use_graph`` = True / False / "auto" (default: replay a hipGraph from the second call with the same shape on),
+        ``defer_guard=True`` returns without the call's one stream synchronisation (several sample() calls can then be in flight on several
+        streams); ``transformer.finish_pending()`` completes them."""
         self.eval()
         if cond.ndim == 2:  # raw wave
             cond = self.mel_spec(cond)
@@ -108,7 +110,7 @@ class CFM(nn.Module):
             # forms compute the same thing
             use_mask = mask is not None and bool((duration != max_dur).any())
             out, trajectory = native(cond, text, lens, duration, y0, t, steps, cfg_strength, method=method, use_mask=use_mask,
-                                     return_trajectory=return_trajectory, use_graph=use_graph)
+                                     return_trajectory=return_trajectory, use_graph=use_graph, defer_guard=defer_guard)
             out = out.to(step_cond.dtype)
         else:
             out, trajectory = self._sample_python(step_cond, cond, cond_mask, text, mask, y0, t, cfg_strength, method, return_trajectory)

@@ -118,6 +118,12 @@ F5_API int f5_sample(f5_plan_t p, int B, int N, const float* cond, const int32_t
               const int32_t* durations, const float* y0, const float* tgrid_host, int steps, float cfg_strength,
               int ode_method, float* out, float* trajectory, int use_graph, f5_stream_t stream);
 
+/* Deferred range-guard check (plan option "residual_guard" = 2): f5_sample then enqueues everything and returns without synchronising, so one
+ * host thread can feed several plans on several streams (F5TTSWrapper.generate runs the text chunks of a call concurrently that way: they
+ * are independent, reference infer/f5tts_wrapper.py:476-533).  f5_sample_finish(plan, stream) synchronises the stream, reads the flag and, if
+ * it was raised, repeats the loop with fp32 residual storage and rewrites the outputs; it is a no-op when nothing is pending. */
+F5_API int f5_sample_finish(f5_plan_t p, f5_stream_t stream);
+
 /* TextEmbedding.forward (dit.py:49-79): text ids [B, nt] (-1 padded) -> dev f32 [B, N, text_dim] */
 F5_API int f5_text_embed(f5_plan_t p, int B, int N, const int32_t* text, int nt, int drop_text, float* out, f5_stream_t stream);
 
@@ -155,7 +161,8 @@ F5_API int f5_plan_timing_site(f5_plan_t p, int site, float* avg_ms, int* launch
  * Residual-stream storage of the bf16 mode: key "residual_f16": 1 = fp16 (saturating), 0 = fp32, -1 = the process-wide
  * knob (default: fp16); key "residual_guard" (default 1): f5_sample reads, after the ODE loop, the flag word the LayerNorm passes raise when
  * an element of the fp16 stream reaches +-65504 or is NaN, repeats the loop with fp32 storage and keeps fp32 storage for this plan
- * (f5_sample then synchronises the stream once per call; 0 = no read, fully asynchronous, clipping goes unnoticed). */
+ * (f5_sample then synchronises the stream once per call; 0 = no read, fully asynchronous, clipping goes unnoticed; 2 = the read is
+ * deferred to f5_sample_finish). */
 F5_API int f5_plan_set_option(f5_plan_t p, const char* key, int value);
 /* reads an option back; besides the keys above: "residual_fallbacks" = f5_sample calls of this plan that were repeated with fp32 residual
  * storage because the range guard fired ("residual_f16" then reads 0). */

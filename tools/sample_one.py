@@ -1,5 +1,6 @@
 """One eager CFM.sample() at a bench shape with few Euler steps (target of rocprofv3 counter passes):
-   python3 tools/sample_one.py [B N NFE] [--events]     (--events: the HIP event pairs of bench.py's in-situ timing pass around every block kernel)"""
+   python3 tools/sample_one.py [B N NFE] [--events] [--repeat=K]
+   --events: the HIP event pairs of bench.py's in-situ timing pass around every block kernel; --repeat=K: K samples, a device sync after each"""
 import os
 import sys
 
@@ -10,6 +11,7 @@ import bench  # noqa: E402
 from eraxvif5tts_amd.model import CFM, DiT  # noqa: E402
 
 events = "--events" in sys.argv
+repeat = max([int(a.split("=")[1]) for a in sys.argv if a.startswith("--repeat=")] or [1])
 argv = [a for a in sys.argv[1:] if not a.startswith("--")]
 B, N, nfe = [int(a) for a in argv[:3]] if len(argv) >= 3 else (32, 1024, 2)
 model = bench.synth_weights(DiT(**bench.BASE_ARCH, text_num_embeds=bench.VOCAB, mel_dim=100, precision="bf16"))
@@ -20,6 +22,9 @@ if events:
     from eraxvif5tts_amd import _lib
     plan = model.plan(B, N, nfe)
     _lib.check(_lib.load().f5_plan_timing_begin(plan, (7 * 22 + 4) * nfe))
+for _rep in range(repeat - 1):
+    cfm.sample(cond=cond, text=text, duration=dur, lens=lens, steps=nfe, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0, return_trajectory=False, use_graph=False)
+    torch.cuda.synchronize()
 out, _ = cfm.sample(cond=cond, text=text, duration=dur, lens=lens, steps=nfe, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0, return_trajectory=False,
                     use_graph=False)
 torch.cuda.synchronize()
