@@ -245,8 +245,10 @@ def insitu_kernels(model, cfm, batch, B, N, nfe, args):
         # input projection W_x . x (K = 100 padded to 128): 0.2 FLOP per byte -- HBM-bound: reads the noisy mel rows (bf16, 128 wide) and the
         # hoisted part of the embedding, writes the GEMM operand (bf16) and the residual stream
         "input_proj": ("hbm", rows * (128 * es // 2 + D * (xs + es + xs))),
-        "ln1": ("hbm", rows * D * (xs + es + es)),              # read x + the FF branch, write the normalised rows
-        "ln2": ("hbm", rows * D * (xs + es + es + xs + es)),    # read x + both branches, write x and the normalised rows
+        # bf16 mode: the fp16 stream is updated in place by the out-projection / FF2 epilogues, the LayerNorm passes read it and write the
+        # normalised rows; fp32 mode: the passes also read the stored branches and write the stream
+        "ln1": ("hbm", rows * D * ((xs + es) if args.precision == "bf16" else (xs + es + es))),
+        "ln2": ("hbm", rows * D * ((xs + es) if args.precision == "bf16" else (xs + es + es + xs + es))),
     }
     kernels = []
     for i, name in enumerate(_lib.SITES):

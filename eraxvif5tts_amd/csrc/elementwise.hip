@@ -322,6 +322,19 @@ int launch_f32_to_f16(const float* src, void* dst, size_t n, hipStream_t stream,
     return 0;
 }
 
+__global__ __launch_bounds__(256) void f16_to_f32_kernel(const _Float16* __restrict__ src, float* __restrict__ dst, size_t nvec) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) *reinterpret_cast<f32x4*>(dst + i * 4) = load_res4<_Float16>(src + i * 4);
+}
+int launch_f16_to_f32(const void* src, float* dst, size_t n, hipStream_t stream) {
+    if (n == 0) return 0;
+    if (n & 3) return f5_fail(F5_EINVAL, "f16_to_f32: n %% 4 != 0");
+    const size_t nvec = n >> 2;
+    const int grid = (int)(nvec / 256 + 1 < 4096 ? nvec / 256 + 1 : 4096);
+    hipLaunchKernelGGL(f16_to_f32_kernel, dim3(grid), dim3(256), 0, stream, (const _Float16*)src, dst, nvec);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_layernorm_add2(int precision_out, float* x, int ldx, int rows, int dim, const void* y, int ldy, const void* y2, int ymode,
                           const float* mul, const float* add, int mod_bstride, int rows_per_batch, int add_one, void* out, int ldo,
                           hipStream_t stream) {

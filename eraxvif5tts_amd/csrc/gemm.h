@@ -15,7 +15,8 @@ enum GemmMode {
 enum GemmEpi {
     EPI_STORE_T = 0,    // out_t[m][n]  = act(acc + bias[n])                                (activation dtype)
     EPI_STORE_F32 = 1,  // out_f[m][n]  = act(acc + bias[n])                                (f32)
-    EPI_RESID = 2,      // out_f[m][n] += gate[b(m)][n] * act(acc + bias[n]), skipped where rowmask[m]==0
+    EPI_RESID = 2,      // out_f[m][n] += gate[b(m)][n] * act(acc + bias[n]), skipped where rowmask[m]==0 (out_f holds fp16 when add2_f16:
+                        // the residual stream of the bf16 mode, updated in place by the attention out-projection and the second FF linear)
     EPI_ADD2 = 3,       // v = acc + bias[n] + addend[m][n];  out_t[m][n] = v;  out_f[m][n] = v
     EPI_ROPE_T = 4,     // out_t = rope(acc + bias) on the q/k columns of the first pe heads (fused QKV projection)
     EPI_GATE_T = 5      // out_t[m][n] = gate[b(m)][n] * act(acc + bias[n]), 0 where rowmask[m]==0  (store-only residual branch;
@@ -36,7 +37,7 @@ struct GemmParams {
     int ldof;
     const float* addend;  // EPI_ADD2
     int ldadd;
-    int add2_f16;  // EPI_ADD2: `addend` and `out_f` hold fp16 elements (same leading dimensions, in elements): the bf16 mode's residual stream
+    int add2_f16;  // EPI_ADD2 / EPI_RESID: `addend` and `out_f` hold fp16 elements (same leading dimensions, in elements): the bf16 mode's residual stream
     const float* gate;  // EPI_RESID: gate[b * gate_bstride + n] or null (=1)
     int gate_bstride;
     int rows_per_batch;      // sequence length N_seq: b(m) = m / rows_per_batch, position = m % rows_per_batch

@@ -53,6 +53,17 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmParams& p, int m, int n
     } else if constexpr (EPI == EPI_RESID) {
         if (p.rowmask && p.rowmask[m] == 0) return;  // attn output of padded query rows is masked_fill'd to 0 (modules.py:499-501)
         const float* g = p.gate ? p.gate + (size_t)(m / p.rows_per_batch) * p.gate_bstride + n : nullptr;
+        if (p.add2_f16) {  // the residual stream of the bf16 production mode: fp16 storage (saturating), fp32 arithmetic
+            _Float16* d = reinterpret_cast<_Float16*>(p.out_f) + (size_t)m * p.ldof + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < nvalid) {
+                    float t = apply_act(v[r], p.act);
+                    if (g) t *= g[r];
+                    d[r] = (_Float16)__builtin_amdgcn_fmed3f((float)d[r] + t, -65504.0f, 65504.0f);
+                }
+            return;
+        }
         float* dst = p.out_f + (size_t)m * p.ldof + n;
         const bool vec = nvalid == 4 && (p.ldof & 3) == 0;
         float o[4];

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
     int nwide;
     [[maybe_unused]] unsigned keepbits = 0xffu;  // lean epilogue: bit j = row (j * 16 + fr) of this wave's token rows is kept
     auto prep_epilogue = [&]() {
-        if constexpr (EPI == EPI_GATE_T) {
+        if constexpr (EPI == EPI_GATE_T || EPI == EPI_RESID) {
             const int mw = m0 + wm * WM;
             if (p.rowmask && p.rowbits && mw < p.M) keepbits = (unsigned)p.rowbits[(mw >> 7) * 16 + fr] >> ((mw & 127) >> 4);
         }
@@ -276,7 +276,14 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
             for (int jj = 0; jj < JG; ++jj) {
                 keep[jj] = p.rowmask ? p.rowmask[mrow[jj]] != 0 : true;
 #pragma unroll
-                for (int i = 0; i < NI; ++i) aux[jj][i] = *reinterpret_cast<const f32x4*>(p.out_f + (size_t)mrow[jj] * p.ldof + ncol[i]);
+                for (int i = 0; i < NI; ++i) {
+                    if (p.add2_f16) {  // fp16 residual stream (bf16 production mode)
+                        const f16x4_t hv = *reinterpret_cast<const f16x4_t*>(reinterpret_cast<const _Float16*>(p.out_f) + (size_t)mrow[jj] * p.ldof + ncol[i]);
+                        aux[jj][i] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+                    } else {
+                        aux[jj][i] = *reinterpret_cast<const f32x4*>(p.out_f + (size_t)mrow[jj] * p.ldof + ncol[i]);
+                    }
+                }
             }
         }
         static_for<JG>([&](auto jc) {
@@ -347,7 +354,16 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
                             }
                         }
                     } else if constexpr (EPI == EPI_RESID) {
-                        if (ok && keep[jj]) *reinterpret_cast<f32x4*>(p.out_f + mr * p.ldof + ncol[i]) = vals[i];
+                        if (ok && keep[jj]) {
+                            if (p.add2_f16) {
+                                f16x4_t hv;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) hv[e] = (_Float16)__builtin_amdgcn_fmed3f(vals[i][e], -65504.0f, 65504.0f);
+                                *reinterpret_cast<f16x4_t*>(reinterpret_cast<_Float16*>(p.out_f) + mr * p.ldof + ncol[i]) = hv;
+                            } else {
+                                *reinterpret_cast<f32x4*>(p.out_f + mr * p.ldof + ncol[i]) = vals[i];
+                            }
+                        }
                     }
                 });
             }
@@ -475,6 +491,65 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
             *reinterpret_cast<u32x4*>(hrow + jo * p.ldof + 32) = pair_swap(to_h(v2), to_h(v3));
         });
     };
+    // ---- lean form of EPI_RESID on the fp16 residual stream (attention out-projection and second FF linear of the bf16 mode): the stream tile
+    //      is read at the position a lane stores, brought to the accumulator layout by the inverse of pair_swap, x += gate * acc (the bias is in
+    //      the accumulator's start value), written back through pair_swap: 16-byte accesses throughout.  Masked query rows keep their value.
+    [[maybe_unused]] auto lean_resid_f16 = [&]() __attribute__((always_inline)) {
+        const size_t row0 = (size_t)(m0 + wm * WM + fr);
+        _Float16* hrow = reinterpret_cast<_Float16*>(p.out_f) + row0 * p.ldof + nwide;
+        u32x4 adA[2], adB[2];  // stream values of the even / odd token tile in flight (named apart: no runtime-indexed arrays)
+        auto load_x = [&](auto jc, u32x4 (&dst)[2]) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            dst[0] = *reinterpret_cast<const u32x4*>(hrow + (size_t)16 * j * p.ldof);
+            dst[1] = *reinterpret_cast<const u32x4*>(hrow + (size_t)16 * j * p.ldof + 32);
+        };
+        auto widen_h = [](unsigned lo, unsigned hi) __attribute__((always_inline)) {
+            const f16x4_t h = __builtin_bit_cast(f16x4_t, u32x2{lo, hi});
+            return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        };
+        auto to_h = [](const f32x4& v) __attribute__((always_inline)) {
+            f16x4_t h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (_Float16)__builtin_amdgcn_fmed3f(v[e], -65504.0f, 65504.0f);
+            return __builtin_bit_cast(bf16x4, h);  // 8 bytes through pair_swap's bit shuffle
+        };
+        load_x(std::integral_constant<int, 0>{}, adA);
+        static_for<MI>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j + 1 < MI) {
+                if constexpr ((j + 1) & 1)
+                    load_x(std::integral_constant<int, j + 1>{}, adB);
+                else
+                    load_x(std::integral_constant<int, j + 1>{}, adA);
+            }
+            const bool keep = (keepbits >> j) & 1u;
+            f32x4 x0, x1, x2, x3;
+            {
+                const u32x4 q = (j & 1) ? adB[0] : adA[0];
+                const u32x2 s0 = __builtin_amdgcn_permlane16_swap(q[0], q[2], false, false);
+                const u32x2 s1 = __builtin_amdgcn_permlane16_swap(q[1], q[3], false, false);
+                x0 = widen_h(s0[0], s1[0]);
+                x1 = widen_h(s0[1], s1[1]);
+            }
+            {
+                const u32x4 q = (j & 1) ? adB[1] : adA[1];
+                const u32x2 s0 = __builtin_amdgcn_permlane16_swap(q[0], q[2], false, false);
+                const u32x2 s1 = __builtin_amdgcn_permlane16_swap(q[1], q[3], false, false);
+                x2 = widen_h(s0[0], s1[0]);
+                x3 = widen_h(s0[1], s1[1]);
+            }
+            const f32x4 v0 = keep ? x0 + acc[0][j] * gate4[0] : x0;
+            const f32x4 v1 = keep ? x1 + acc[1][j] * gate4[1] : x1;
+            const f32x4 v2 = keep ? x2 + acc[2][j] * gate4[2] : x2;
+            const f32x4 v3 = keep ? x3 + acc[3][j] * gate4[3] : x3;
+            const size_t jo = (size_t)16 * j;
+            *reinterpret_cast<u32x4*>(hrow + jo * p.ldof) = pair_swap(to_h(v0), to_h(v1));
+            *reinterpret_cast<u32x4*>(hrow + jo * p.ldof + 32) = pair_swap(to_h(v2), to_h(v3));
+        });
+    };
+    // (Tried and dropped, round 3, in-situ A/B on one box, gpurun_out/r3o_*: requesting the tile's first stream values three K-steps before
+    //  the tile ends -- no effect, 252 registers; fetching the next tile's gate vectors / row-mask byte ahead of this tile's stores, so that
+    //  the compiler's vmcnt(0) in front of their first use does not sit behind the stores -- out-projection 171 -> 187 us, FF2 293 -> 308 us.)
     // whole tile + the operand forms the lean epilogue assumes; anything else takes the generic path
     [[maybe_unused]] auto lean_ok = [&]() {
         if constexpr (!(EPI == EPI_STORE_T || EPI == EPI_GATE_T || EPI == EPI_ROPE_T)) return false;
@@ -484,7 +559,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
         return ok;
     };
     auto epilogue = [&]() {
-        if constexpr (P30) {  // the launcher guarantees whole tiles and lean operand forms: no generic code in this build
+        if constexpr (P30 && EPI == EPI_RESID) {  // (the launcher guarantees whole tiles, the fp16 stream and lean operand forms)
+            lean_resid_f16();
+            return;
+        } else if constexpr (P30) {  // the launcher guarantees whole tiles and lean operand forms: no generic code in this build
             if (p.act == ACT_GELU_TANH)
                 lean_epilogue(std::integral_constant<int, ACT_GELU_TANH>{});
             else
@@ -493,6 +571,12 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
         } else if constexpr (EPI == EPI_ADD2 && NI == 4) {
             if (p.lean_epi && p.add2_f16 && p.act == ACT_NONE && m0 + BM <= p.M && n0 + BN <= p.N && ((p.ldo | p.ldof | p.ldadd) & 7) == 0) {
                 lean_add2_f16();
+                return;
+            }
+        } else if constexpr (EPI == EPI_RESID && NI == 4) {
+            if (p.lean_epi && p.add2_f16 && p.act == ACT_NONE && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldof & 7) == 0 && p.bias != nullptr &&
+                (!p.gate || p.gate_bstride == 0) && (!p.rowmask || p.rowbits)) {
+                lean_resid_f16();
                 return;
             }
         } else if constexpr (EPI == EPI_STORE_T || EPI == EPI_GATE_T || EPI == EPI_ROPE_T) {
@@ -696,14 +780,16 @@ template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmPa
     // persistent grid (one workgroup per CU walking tiles, next tile's first K-steps prefetched under the epilogue, bias folded into the
     // accumulator start): whole tiles with the lean epilogue's operand forms only
     // (K >= 128: the last K-step of a tile must be one that still waits for the next tile's first stage, see the main loop)
-    const bool persist_ok = MODE == GEMM_DENSE && (EPI == EPI_STORE_T || EPI == EPI_GATE_T || EPI == EPI_ROPE_T) && p.M % 256 == 0 && p.K >= 128 &&
-                            p.N % 256 == 0 && (p.ldo & 7) == 0 && p.bias && p.out_t && (p.act == ACT_NONE || p.act == ACT_GELU_TANH) &&
-                            (EPI != EPI_GATE_T || (p.gate_bstride == 0 && (!p.rowmask || p.rowbits))) && (EPI != EPI_ROPE_T || p.rows_per_batch >= 128);
+    const bool store_ok = (EPI == EPI_STORE_T || EPI == EPI_GATE_T || EPI == EPI_ROPE_T) && (p.ldo & 7) == 0 && p.out_t && (p.act == ACT_NONE || p.act == ACT_GELU_TANH) &&
+                          (EPI != EPI_GATE_T || (p.gate_bstride == 0 && (!p.rowmask || p.rowbits))) && (EPI != EPI_ROPE_T || p.rows_per_batch >= 128);
+    const bool resid_ok = EPI == EPI_RESID && p.add2_f16 && p.out_f && (p.ldof & 7) == 0 && p.act == ACT_NONE && (!p.gate || p.gate_bstride == 0) &&
+                          (!p.rowmask || p.rowbits);  // in-place update of the fp16 residual stream
+    const bool persist_ok = MODE == GEMM_DENSE && (store_ok || resid_ok) && p.M % 256 == 0 && p.K >= 128 && p.N % 256 == 0 && p.bias;
     if constexpr (BN == 256) {
         if (g_gemm_variant == 0)
             hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, MODE, EPI, 0, 4>), grid, block, 0, stream, p, tiles_n, nblocks);
         else if (g_gemm_persist && persist_ok) {
-            if constexpr (EPI == EPI_STORE_T || EPI == EPI_GATE_T || EPI == EPI_ROPE_T)
+            if constexpr (EPI == EPI_STORE_T || EPI == EPI_GATE_T || EPI == EPI_ROPE_T || EPI == EPI_RESID)
                 hipLaunchKernelGGL((gemm_fast_kernel<BN, WM, GEMM_DENSE, EPI, 30, 5>), dim3(nblocks < persist_grid() ? nblocks : persist_grid()), block,
                                    0, stream, p, tiles_n, nblocks);
         } else

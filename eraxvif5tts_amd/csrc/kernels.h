@@ -28,6 +28,7 @@ struct PrefetchSet {
 };
 // saturating, n % 4 == 0; `sat` (device word or null) is set to 1 when an element is at or beyond fp16's range, or NaN
 int launch_f32_to_f16(const float* src, void* dst, size_t n, hipStream_t stream, unsigned* sat = nullptr);
+int launch_f16_to_f32(const void* src, float* dst, size_t n, hipStream_t stream);  // n % 4 == 0
 // residual stream read from xin (fp32, or fp16 when xin_f16) and, ymode 1 / 3, written to xout (fp32 / fp16): elementwise.hip
 int launch_layernorm_res(int precision_out, const void* xin, int xin_f16, void* xout, int xout_f16, int ldx, int rows, int dim, const void* y, int ldy,
                          const void* y2, int ymode, const float* mul, const float* add, int mod_bstride, int rows_per_batch, int add_one, void* out,

@@ -614,6 +614,7 @@ int g_w_prefetch = 16384;  // tuning knob ("w_prefetch"): LayerNorm passes prefe
                             // (0 = never).  M = 8192: +2.3 %, M = 2048: +2.9 % mel-frames/s; M = 65536: no effect (each weight line serves 256 token tiles there)
 int g_res_f16 = 1;   // tuning knob ("residual_f16"): bf16 production mode keeps the residual stream in fp16 from the first block on (0 = fp32)
 int g_ln_defer = 1;  // tuning knob ("ln_defer"): write the residual stream once per DiT block (0 = after every LayerNorm pass)
+int g_resid_rmw = 1;  // tuning knob ("resid_rmw"): see dit_eval
 int g_sync_evals = 0;  // diagnostic knob ("sync_evals"): an eager sample() synchronises the stream after every network evaluation, which bounds the
                        // number of dispatches in flight (profiles/r3_rocprof_pmc_sigsegv.md: rocprofv3 --pmc died under ~5 400 queued dispatches)
 
@@ -743,6 +744,11 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         F5_TRY(timed(p, F5_SITE_CONV, st, [&] { return run_gemm(p, g, GEMM_CONV31, li == 0 ? EPI_STORE_T : EPI_GATE_T, st); }));
     }
 
+    // In-place residual updates (bf16 production mode, one time per evaluation): the fp16 stream is updated by the epilogues of the attention
+    // out-projection and of the second FF linear (EPI_RESID on the fp16 stream) and the LayerNorm passes only read it (block 0 first adds the
+    // position-conv branch): 1 024 MiB of stream + branch traffic per block instead of 1 280, and the two passes shrink from 384 + 640 MiB to
+    // 256 + 256.  Otherwise (fp32 stream, stage taps, per-sample time rows, knob "resid_rmw" = 0): store-only branches, adds fused into the passes.
+    const bool rmw = r16 && mod_bstride == 0 && g_resid_rmw;
     for (int l = 0; l < c.depth; ++l) {
         const BlockW& b = m->blocks[l];
         const float* ml = modp + (size_t)l * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp (modules.py:312)
@@ -762,6 +768,9 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         PrefetchSet pf2{{b.w_ff2, l + 1 < c.depth ? m->blocks[l + 1].w_qkv : nullptr, nullptr, nullptr},
                         {(unsigned)(D * ff * wes), (unsigned)(3 * inner * D * wes), 0u, 0u}};
         F5_TRY(timed(p, F5_SITE_LN1, st, [&] {
+            if (rmw)
+                return launch_layernorm_res(P, xin, 1, xout, 1, D, rows, D, l == 0 ? p->yT : nullptr, D, nullptr, 1, ml + D, ml, mod_bstride, N, 1, p->hT, D, st,
+                                            wpf ? &pf1 : nullptr, sat, 1 | (l << 4));
             return launch_layernorm_res(P, xin, in16, xout, r16, D, rows, D, p->yT, D, nullptr, defer ? 2 : 1, ml + D, ml, mod_bstride, N, 1, p->hT, D, st,
                                         wpf ? &pf1 : nullptr, sat, 1 | (l << 4));
         }));
@@ -811,9 +820,18 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         g.bias = b.b_o; g.out_t = defer ? p->yA : p->yT; g.ldo = D; g.gate = ml + 2 * D; g.gate_bstride = mod_bstride; g.rows_per_batch = N;
         g.rowmask = mask;
         g.rowbits = (mask && mask == p->rowbits_src) ? p->rowbits : nullptr;
-        F5_TRY(timed(p, F5_SITE_OUT, st, [&] { return run_gemm(p, g, GEMM_DENSE, EPI_GATE_T, st); }));
+        if (rmw) {
+            g.out_t = nullptr;
+            g.out_f = reinterpret_cast<float*>(p->xres16);
+            g.ldof = D;
+            g.add2_f16 = 1;
+        }
+        F5_TRY(timed(p, F5_SITE_OUT, st, [&] { return run_gemm(p, g, GEMM_DENSE, rmw ? EPI_RESID : EPI_GATE_T, st); }));
         // x += y; n2 = LN(x) * (1 + scale_mlp) + shift_mlp
         F5_TRY(timed(p, F5_SITE_LN2, st, [&] {
+            if (rmw)
+                return launch_layernorm_res(P, xin, 1, xout, 1, D, rows, D, nullptr, D, nullptr, 1, ml + 4 * D, ml + 3 * D, mod_bstride, N, 1, p->hT, D, st,
+                                            wpf ? &pf2 : nullptr, sat, 2 | (l << 4));
             return launch_layernorm_res(P, xin, in16, xout, r16, D, rows, D, p->yT, D, defer ? p->yA : nullptr, defer ? 3 : 1, ml + 4 * D, ml + 3 * D,
                                         mod_bstride, N, 1, p->hT, D, st, wpf ? &pf2 : nullptr, sat, 2 | (l << 4));
         }));
@@ -825,12 +843,22 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         g = gp_zero();
         g.A = p->ffh; g.lda = ff; g.W = b.w_ff2; g.ldw = ff; g.M = rows; g.N = D; g.K = ff;
         g.bias = b.b_ff2; g.out_t = p->yT; g.ldo = D; g.gate = ml + 5 * D; g.gate_bstride = mod_bstride; g.rows_per_batch = N;
-        F5_TRY(timed(p, F5_SITE_FF2, st, [&] { return run_gemm(p, g, GEMM_DENSE, EPI_GATE_T, st); }));
+        if (rmw) {
+            g.out_t = nullptr;
+            g.out_f = reinterpret_cast<float*>(p->xres16);
+            g.ldof = D;
+            g.add2_f16 = 1;
+        }
+        F5_TRY(timed(p, F5_SITE_FF2, st, [&] { return run_gemm(p, g, GEMM_DENSE, rmw ? EPI_RESID : EPI_GATE_T, st); }));
+
     }
     const float* mf = modp + (size_t)c.depth * 6 * D;  // final AdaLN: (scale, shift) (modules.py:333)
     // (no stage tap: the stream itself is not needed any more, so the last add is not written back)
-    F5_TRY(launch_layernorm_res(P, r16 ? p->xres16 : (const void*)p->xres, r16, r16 ? p->xres16 : (void*)p->xres, r16, D, rows, D, p->yT, D, nullptr,
-                                defer ? 2 : 1, mf, mf + D, mod_bstride, N, 1, p->hT, D, st, nullptr, sat, 3));
+    if (rmw)  // (the stream already holds every branch)
+        F5_TRY(launch_layernorm_res(P, p->xres16, 1, p->xres16, 1, D, rows, D, nullptr, D, nullptr, 1, mf, mf + D, mod_bstride, N, 1, p->hT, D, st, nullptr, sat, 3));
+    else
+        F5_TRY(launch_layernorm_res(P, r16 ? p->xres16 : (const void*)p->xres, r16, r16 ? p->xres16 : (void*)p->xres, r16, D, rows, D, p->yT, D, nullptr,
+                                    defer ? 2 : 1, mf, mf + D, mod_bstride, N, 1, p->hT, D, st, nullptr, sat, 3));
     F5_TRY(tap_f32(p, "blk" + std::to_string(c.depth - 1) + ".out", p->xres, D, rows, D, st));
     F5_TRY(tap_t(p, "final_norm", p->hT, D, rows, D, st));
     g = gp_zero();

@@ -47,7 +47,8 @@ extern "C" int f5_op_linear_fused(int kernel, int epi, int M, int N, int K, cons
                                   f5_stream_t stream) {
     F5_TRY(f5_check_device());
     if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !out) return f5_fail(F5_EINVAL, "bad argument");
-    if (!(epi == EPI_STORE_T || epi == EPI_GATE_T || epi == EPI_ROPE_T)) return f5_fail(F5_EINVAL, "f5_op_linear_fused: epilogue %d", epi);
+    if (!(epi == EPI_STORE_T || epi == EPI_GATE_T || epi == EPI_ROPE_T || epi == EPI_RESID)) return f5_fail(F5_EINVAL, "f5_op_linear_fused: epilogue %d", epi);
+    if (epi == EPI_RESID && ((size_t)M * N) % 4 != 0) return f5_fail(F5_EINVAL, "f5_op_linear_fused: M * N must be a multiple of 4 for the in-place form");
     if (epi == EPI_ROPE_T && (!rope || seq <= 0 || M % seq != 0 || N % 3 != 0 || (N / 3) % 64 != 0)) return f5_fail(F5_EINVAL, "bad RoPE arguments");
     hipStream_t st = (hipStream_t)stream;
     const int Kp = (int)round_up(K, 64), Mp = (int)round_up(M, 256), Np = (int)round_up(N, 256);
@@ -58,7 +59,7 @@ extern "C" int f5_op_linear_fused(int kernel, int epi, int M, int N, int K, cons
     do {
         if ((rc = a.alloc(&At, (size_t)Mp * Kp * 2))) break;
         if ((rc = a.alloc(&Wt, (size_t)Np * Kp * 2))) break;
-        if ((rc = a.alloc(&Ot, (size_t)Mp * N * 2))) break;
+        if ((rc = a.alloc(&Ot, (size_t)Mp * N * 2))) break;  // bf16 output, or the fp16 stream of the in-place form
         if ((rc = a.alloc_t(&bits, (size_t)(Mp / 128 + 1) * 16))) break;
         if ((rc = launch_convert_pad(F5_PREC_BF16, A, K, M, K, Kp, At, Kp, st))) break;
         if ((rc = launch_convert_pad(F5_PREC_BF16, W, K, N, K, Kp, Wt, Kp, st))) break;
@@ -66,7 +67,14 @@ extern "C" int f5_op_linear_fused(int kernel, int epi, int M, int N, int K, cons
         memset(&g, 0, sizeof(g));
         g.A = At; g.lda = Kp; g.W = Wt; g.ldw = Kp; g.M = M; g.N = N; g.K = Kp;
         g.bias = bias; g.act = act; g.out_t = Ot; g.ldo = N; g.rows_per_batch = seq > 0 ? seq : M;
-        if (epi == EPI_GATE_T) {
+        if (epi == EPI_RESID) {  // in-place update of the fp16 residual stream: `out` is read (rounded to fp16), updated and written back
+            if ((rc = launch_f32_to_f16(out, Ot, (size_t)M * N, st))) break;
+            g.out_t = nullptr;
+            g.out_f = reinterpret_cast<float*>(Ot);
+            g.ldof = N;
+            g.add2_f16 = 1;
+        }
+        if (epi == EPI_GATE_T || epi == EPI_RESID) {
             g.gate = gate;
             g.rowmask = rowmask;
             if (rowmask) {
@@ -76,7 +84,7 @@ extern "C" int f5_op_linear_fused(int kernel, int epi, int M, int N, int K, cons
         }
         if (epi == EPI_ROPE_T) { g.rope = rope; g.rope_inner = N / 3; g.rope_heads = rope_heads; }
         if ((rc = launch_gemm(g, F5_PREC_BF16, GEMM_DENSE, epi, kernel, st))) break;
-        rc = launch_convert_back(F5_PREC_BF16, Ot, N, M, N, out, N, st);
+        rc = epi == EPI_RESID ? launch_f16_to_f32(Ot, out, (size_t)M * N, st) : launch_convert_back(F5_PREC_BF16, Ot, N, M, N, out, N, st);
     } while (0);
     return sync_and_release(a, st, rc);
 }
@@ -351,7 +359,7 @@ extern "C" int f5_bench_mfma_rate(int random_operands, float* tflops, f5_stream_
     return sync_and_release(a, st, rc);
 }
 
-extern int g_sync_evals, g_attn_persist, g_attn_stagger;
+extern int g_sync_evals, g_attn_persist, g_attn_stagger, g_resid_rmw;
 extern int g_gemm_variant, g_gemm_group, g_gemm_persist_grid, g_gemm_persist, g_gemm_lean, g_ln_defer, g_ln_wide, g_w_prefetch, g_res_f16, g_conv31, g_attn_variant, g_vocos_fft;
 int g_tuning_epoch = 0;
 extern unsigned long long* g_attn_stamp_buf;
@@ -373,6 +381,10 @@ extern "C" int f5_tuning_set(const char* key, int value) {
     ++g_tuning_epoch;  // hipGraphs captured by plans under the previous knob values are dropped at their next use (model.hip)
     if (strcmp(key, "gemm_variant") == 0) {
         g_gemm_variant = value;
+        return 0;
+    }
+    if (strcmp(key, "resid_rmw") == 0) {
+        g_resid_rmw = value != 0;
         return 0;
     }
     if (strcmp(key, "attn_stagger") == 0) {

@@ -192,6 +192,9 @@ F5_API int f5_op_linear(int precision, int kernel, int M, int N, int K, const fl
  *   epi 0: out = act(A W^T + b)                                      FeedForward first linear, reference model/modules.py:258-264
  *   epi 5: out = gate[n] * act(A W^T + b), rows with rowmask[m]==0 -> 0  attention to_out / FF second linear times the AdaLN gate,
  *                                                                    modules.py:499-501,635,639 (gate f32 [N] or NULL, rowmask u8 [M] or NULL)
+ *   epi 2: out = out + gate[n] * (A W^T + b) IN PLACE on the fp16 residual stream (`out` is read, rounded to fp16, updated, returned as f32;
+ *          rows with rowmask[m]==0 keep their value; M * N % 4 == 0): how the attention to_out and the FF second linear update the stream
+ *          in the bf16 production mode, modules.py:635,639
  *   epi 4: out = rope(A W^T + b): fused QKV projection (N = 3*inner), x_transformers rotary on adjacent pairs of the q and k columns
  *          of the first rope_heads heads, modules.py:452-461; rope f32 [seq][32][2] (cos, sin), token position = m % seq
  * kernel: 0 = reference tile kernel, 1 = tuned kernels.  All pointers are device pointers. */

@@ -33,17 +33,18 @@ def op_linear(precision, kernel, A, W, bias=None, act="none"):
     return out.cpu()
 
 
-EPI_STORE_T, EPI_ROPE_T, EPI_GATE_T = 0, 4, 5
+EPI_STORE_T, EPI_RESID, EPI_ROPE_T, EPI_GATE_T = 0, 2, 4, 5
 
 
-def op_linear_fused(kernel, epi, A, W, bias, act="none", gate=None, rowmask=None, rope=None, rope_heads=0, seq=0):
-    """One DiT block linear with its fused bf16 store epilogue (include/f5hip.h: f5_op_linear_fused)."""
+def op_linear_fused(kernel, epi, A, W, bias, act="none", gate=None, rowmask=None, rope=None, rope_heads=0, seq=0, stream_in=None):
+    """One DiT block linear with its fused epilogue (include/f5hip.h: f5_op_linear_fused).  epi 2 updates `stream_in` (the fp16 residual
+    stream, given as f32) in place and returns it."""
     lib = _lib.load()
     M, K = A.shape
     N = W.shape[0]
     dev = [None if t is None else t.cuda().float().contiguous() for t in (A, W, bias, gate, rope)]
     mk = None if rowmask is None else rowmask.cuda().to(torch.uint8).contiguous()
-    out = torch.empty(M, N, device="cuda")
+    out = torch.empty(M, N, device="cuda") if stream_in is None else stream_in.cuda().float().contiguous().clone()
     _lib.check(lib.f5_op_linear_fused(kernel, epi, M, N, K, _lib.ptr(dev[0]), _lib.ptr(dev[1]), _lib.ptr(dev[2]), _lib.ACT[act],
                                       _lib.ptr(dev[3]), _lib.ptr(mk), _lib.ptr(dev[4]), rope_heads, seq, _lib.ptr(out), _lib.stream_ptr()))
     return out.cpu()

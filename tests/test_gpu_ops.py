@@ -120,6 +120,44 @@ def test_linear_fused_epilogues(knobs, epi_name, shape, seq):
         assert torch.count_nonzero(out[~rowmask]) == 0  # masked rows are exact zeros (modules.py:499-501)
 
 
+@pytest.mark.parametrize("knobs", [{}, {"gemm_persist": 0}, {"gemm_persist": 0, "gemm_lean": 0}, {"gemm_variant": 0}],
+                         ids=["default_persistent_grid", "one_tile_per_workgroup", "generic_epilogue", "plain_ring"])
+@pytest.mark.parametrize("shape", [(768, 512, 128), (10240, 1024, 1024), (10240, 1024, 2048), (10301, 1024, 128), (1000, 100, 256)])
+@pytest.mark.parametrize("masked", [False, True], ids=["all_rows", "row_mask"])
+def test_linear_in_place_residual_epilogue(knobs, shape, masked):
+    """x += gate * (A W^T + b) IN PLACE on the fp16 residual stream (how the attention out-projection and the second FF linear update the
+    stream in the bf16 production mode, reference model/modules.py:635,639; masked query rows keep their value, :499-501): the tuned kernel in
+    every schedule the launcher can pick and the reference tile kernel against fp64 on the same fp16-rounded stream; the tuned schedules
+    against each other bit for bit (the fp32 sums and the update are the same in every variant)."""
+    import gpu_helpers as G
+    from eraxvif5tts_amd import _lib
+    lib = _lib.load()
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + 5 * N + K)
+    A, W, b = G.bf16_round(torch.randn(M, K, generator=g)), G.bf16_round(torch.randn(N, K, generator=g) / math.sqrt(K)), torch.randn(N, generator=g)
+    gate = torch.randn(N, generator=g)
+    rowmask = (torch.rand(M, generator=g) > 0.2) if masked else None
+    x = (torch.randn(M, N, generator=g) * 3).half().float()  # the stream as stored
+    upd = gate.double() * (A.double() @ W.double().t() + b.double())
+    if masked:
+        upd = upd * rowmask[:, None].double()
+    ref = (x.double() + upd).float()
+    try:
+        for k, v in knobs.items():
+            _lib.check(lib.f5_tuning_set(k.encode(), v))
+        out = G.op_linear_fused(1, G.EPI_RESID, A, W, b, "none", gate, rowmask, stream_in=x)
+    finally:
+        for k in knobs:
+            _lib.check(lib.f5_tuning_set(k.encode(), {"gemm_lean": 1, "gemm_variant": 1, "gemm_persist": 1}[k]))
+    base = G.op_linear_fused(0, G.EPI_RESID, A, W, b, "none", gate, rowmask, stream_in=x)
+    dflt = G.op_linear_fused(1, G.EPI_RESID, A, W, b, "none", gate, rowmask, stream_in=x)
+    assert rel_l2(out, ref) < 6e-4 and rel_l2(base, ref) < 6e-4   # one fp16 rounding of the result: 2^-11 relative
+    assert torch.equal(out, dflt)                                  # schedule-independent
+    if masked:
+        assert torch.equal(out[~rowmask], x[~rowmask])             # masked rows untouched
+    assert torch.equal(out, out.half().float())                    # the values are fp16 numbers
+
+
 @pytest.mark.parametrize("prec", [P_FP32, P_BF16])
 @pytest.mark.parametrize("B,N,H,masked", [(2, 56, 2, True), (1, 41, 2, False), (2, 200, 3, True), (1, 64, 16, False)])
 def test_attention_reference_kernel(prec, B, N, H, masked):
