@@ -12,6 +12,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libf5hip.so")
 F5_PREC_BF16, F5_PREC_FP32 = 0, 1
 F5_ODE_EULER, F5_ODE_MIDPOINT = 0, 1
 F5_ROPE_ADJACENT, F5_ROPE_HALF_SPLIT = 0, 1
+F5_BACKBONE_DIT, F5_BACKBONE_UNETT = 0, 1
+F5_SKIP = {"concat": 0, "add": 1, "none": 2}
 SITES = ("qkv", "attention", "attn_out", "ff1", "ff2", "ln1", "ln2", "conv31", "input_proj")  # F5_SITE_* order
 ACT = {"none": 0, "gelu_tanh": 1, "gelu_erf": 2, "mish": 3}
 
@@ -22,7 +24,8 @@ class F5HipError(RuntimeError):
 
 class DitConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("dim", "depth", "heads", "dim_head", "ff_inner", "mel_dim", "text_num_embeds", "text_dim",
-                                         "conv_layers", "text_mask_padding", "pe_attn_head", "qk_norm", "long_skip", "precision", "rope_layout")]
+                                         "conv_layers", "text_mask_padding", "pe_attn_head", "qk_norm", "long_skip", "precision", "rope_layout",
+                                         "backbone", "skip_connect")]
 
 
 class VocosConfig(C.Structure):

@@ -354,6 +354,116 @@ int launch_layernorm(int precision_out, const float* x, int ldx, int rows, int d
                                 out, ldo, stream);
 }
 
+// ----------------------------------------------------------------------------- UNetT (reference model/backbones/unett.py): RMSNorm and the time-token plumbing
+// x_transformers.RMSNorm as unett.py:146,156,175 uses it: out = x / max(||x||_2, 1e-12) * sqrt(dim) * g   (one wavefront per row, fp32 math)
+template <typename TO>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, int ldx, int rows, int dim, const float* __restrict__ g, TO* __restrict__ out, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * ldx;
+    float q = 0.f;
+    for (int c = lane * 4; c < dim; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+        q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    const float nrm = sqrtf(wave_sum(q));
+    const float sc = sqrtf((float)dim) / fmaxf(nrm, 1e-12f);
+    TO* orow = out + (size_t)row * ldo;
+    for (int c = lane * 4; c < dim; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + c);
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = v[e] * sc * gv[e];
+        if constexpr (sizeof(TO) == 2)
+            *reinterpret_cast<bf16x4*>(orow + c) = bf16x4{(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+        else
+            *reinterpret_cast<f32x4*>(orow + c) = f32x4{o[0], o[1], o[2], o[3]};
+    }
+}
+int launch_rmsnorm(int precision_out, const float* x, int ldx, int rows, int dim, const float* g, void* out, int ldo, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    if (dim % 4 != 0 || (ldx & 3) || (ldo & 3)) return f5_fail(F5_EINVAL, "rmsnorm: dim=%d unsupported", dim);
+    dim3 grid(cdiv(rows, 4)), block(256);
+    if (precision_out == F5_PREC_BF16)
+        hipLaunchKernelGGL((rmsnorm_kernel<bf16_t>), grid, block, 0, stream, x, ldx, rows, dim, g, (bf16_t*)out, ldo);
+    else
+        hipLaunchKernelGGL((rmsnorm_kernel<float>), grid, block, 0, stream, x, ldx, rows, dim, g, (float*)out, ldo);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+// unett.py:211-213: the time embedding is prepended as one more token.  dst[b][0] = temb[b]; dst[b][1 + n] = h[b][n] + branch[b][n]
+// (h = input projection, branch = the position-conv branch in the activation dtype: InputEmbedding's x + conv_pos_embed(x), unett.py:96-97)
+template <typename TB>
+__global__ __launch_bounds__(256) void pack_time_token_kernel(const float* __restrict__ h, const TB* __restrict__ branch, const float* __restrict__ temb,
+                                                              int temb_bstride, int B, int N, int D, float* __restrict__ dst) {
+    const int row = blockIdx.x;  // b * (N + 1) + s
+    const int b = row / (N + 1), sidx = row - b * (N + 1);
+    float* d = dst + (size_t)row * D;
+    if (sidx == 0) {
+        for (int c = threadIdx.x; c < D; c += 256) d[c] = temb[(size_t)b * temb_bstride + c];
+    } else {
+        const size_t src = (size_t)b * N + (sidx - 1);
+        for (int c = threadIdx.x; c < D; c += 256) d[c] = h[src * D + c] + to_f32(branch[src * D + c]);
+    }
+}
+int launch_pack_time_token(int precision, const float* h, const void* branch, const float* temb, int temb_bstride, int B, int N, int D, float* dst,
+                           hipStream_t stream) {
+    if (B * (N + 1) <= 0) return 0;
+    if (precision == F5_PREC_BF16)
+        hipLaunchKernelGGL((pack_time_token_kernel<bf16_t>), dim3(B * (N + 1)), dim3(256), 0, stream, h, (const bf16_t*)branch, temb, temb_bstride, B, N, D, dst);
+    else
+        hipLaunchKernelGGL((pack_time_token_kernel<float>), dim3(B * (N + 1)), dim3(256), 0, stream, h, (const float*)branch, temb, temb_bstride, B, N, D, dst);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+// unett.py:214: mask = F.pad(mask, (1, 0), value=1)
+__global__ __launch_bounds__(256) void pad_mask_kernel(const uint8_t* __restrict__ mask, int B, int N, uint8_t* __restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * (N + 1)) return;
+    const int b = i / (N + 1), sidx = i - b * (N + 1);
+    dst[i] = sidx == 0 ? (uint8_t)1 : mask[(size_t)b * N + (sidx - 1)];
+}
+int launch_pad_mask(const uint8_t* mask, int B, int N, uint8_t* dst, hipStream_t stream) {
+    hipLaunchKernelGGL(pad_mask_kernel, dim3(cdiv(B * (N + 1), 256)), dim3(256), 0, stream, mask, B, N, dst);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+// unett.py:246: [:, 1:, :] -- drop the time token.  src [B * (N + 1), cols] -> dst [B * N, cols]
+__global__ __launch_bounds__(256) void drop_time_token_kernel(const float* __restrict__ src, int B, int N, int cols, float* __restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * N * cols) return;
+    const size_t row = i / cols;
+    const int c = (int)(i - row * cols);
+    const size_t b = row / N, n = row - b * N;
+    dst[i] = src[(b * (N + 1) + n + 1) * cols + c];
+}
+int launch_drop_time_token(const float* src, int B, int N, int cols, float* dst, hipStream_t stream) {
+    const size_t total = (size_t)B * N * cols;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(drop_time_token_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, B, N, cols, dst);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+// x += y (skip_connect_type "add", unett.py:237-238); n % 4 == 0
+__global__ __launch_bounds__(256) void add_f32_kernel(float* __restrict__ x, const float* __restrict__ y, size_t nvec) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(x + i * 4);
+        a += *reinterpret_cast<const f32x4*>(y + i * 4);
+        *reinterpret_cast<f32x4*>(x + i * 4) = a;
+    }
+}
+int launch_add_f32(float* x, const float* y, size_t n, hipStream_t stream) {
+    if (n == 0) return 0;
+    if (n & 3) return f5_fail(F5_EINVAL, "add_f32: n %% 4 != 0");
+    const size_t nvec = n >> 2;
+    hipLaunchKernelGGL(add_f32_kernel, dim3((unsigned)(nvec / 256 + 1 < 4096 ? nvec / 256 + 1 : 4096)), dim3(256), 0, stream, x, y, nvec);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
 // ----------------------------------------------------------------------------- depthwise conv k=7 + LayerNorm(affine)
 template <typename TO, int MAXV>
 __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict__ x, int B, int N, int C, const float* __restrict__ wt,

@@ -34,6 +34,15 @@ int launch_layernorm_res(int precision_out, const void* xin, int xin_f16, void* 
                          const void* y2, int ymode, const float* mul, const float* add, int mod_bstride, int rows_per_batch, int add_one, void* out,
                          int ldo, hipStream_t stream, const PrefetchSet* prefetch = nullptr, unsigned* sat = nullptr /* range guard of the fp16 stream */,
                          int sat_tag = 0 /* diagnostics: pass kind | DiT block << 4 */);
+// ---- UNetT (reference model/backbones/unett.py)
+// x_transformers.RMSNorm: out[r] = x[r] / max(||x[r]||, 1e-12) * sqrt(dim) * g    (x f32; out in the activation dtype of precision_out)
+int launch_rmsnorm(int precision_out, const float* x, int ldx, int rows, int dim, const float* g, void* out, int ldo, hipStream_t stream);
+// dst [B * (N + 1), D] f32: row b * (N + 1) = temb[b * temb_bstride ..], rows after it = h[b] + branch[b] (branch in the activation dtype)
+int launch_pack_time_token(int precision, const float* h, const void* branch, const float* temb, int temb_bstride, int B, int N, int D, float* dst,
+                           hipStream_t stream);
+int launch_pad_mask(const uint8_t* mask, int B, int N, uint8_t* dst, hipStream_t stream);                      // [B, N] -> [B, N + 1], leading 1
+int launch_drop_time_token(const float* src, int B, int N, int cols, float* dst, hipStream_t stream);          // [B * (N + 1), cols] -> [B * N, cols]
+int launch_add_f32(float* x, const float* y, size_t n, hipStream_t stream);                                    // x += y, n % 4 == 0
 // depthwise Conv1d(k=7, pad=3) along the sequence (+bias) then LayerNorm(eps 1e-6, affine) -> activation dtype
 // x f32 [B*N, C]; wt f32 [7][C] (tap-major); out [B*N, C]
 int launch_dwconv7_ln(int precision_out, const float* x, int B, int N, int C, const float* wt, const float* cbias, const float* ln_w,

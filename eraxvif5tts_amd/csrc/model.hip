@@ -25,6 +25,9 @@ static const int MELP = 128;  // mel channels padded to one MFMA k-block multipl
 struct BlockW {
     void *w_qkv = nullptr, *w_o = nullptr, *w_ff1 = nullptr, *w_ff2 = nullptr;
     float *b_qkv = nullptr, *b_o = nullptr, *b_ff1 = nullptr, *b_ff2 = nullptr;
+    // UNetT layers (unett.py:139-171): skip projection [D, 2D] of the later half (concat type), RMSNorm gains
+    void* w_skip = nullptr;
+    float *g_attn = nullptr, *g_ff = nullptr;
 };
 struct TextBlockW {
     float *dw_wt = nullptr, *dw_b = nullptr, *ln_w = nullptr, *ln_b = nullptr, *b1 = nullptr, *gamma = nullptr, *beta = nullptr, *b2 = nullptr;
@@ -48,6 +51,8 @@ struct f5_model_s {
     float* b_conv[2] = {nullptr, nullptr};
     void* w_out = nullptr;
     float* b_out = nullptr;
+    float* g_out = nullptr;  // UNetT: norm_out.g
+    int td_pad = 0;          // text_dim rounded up to the GEMM's K granule (E2-TTS: text_dim = mel_dim = 100)
     float inv_freq[32];
 };
 
@@ -100,6 +105,12 @@ struct f5_plan_s {
     int res_f16 = -1;              // plan option "residual_f16": -1 = the process-wide knob, 0 = fp32 storage, 1 = fp16 storage
     int sat_check = 1;             // plan option "residual_guard": 0 = never read the flag (f5_sample stays fully asynchronous)
     PendingSample pending;
+    // UNetT (unett.py:185-253): the stream carries one time token per utterance in front of the frames
+    float* xin_res = nullptr;          // input projection + hoisted embedding, before the time token is prepended [B*N, D]
+    float* vout_s = nullptr;           // proj_out over all N + 1 tokens [B*(N+1), MELP]
+    void* catT = nullptr;              // cat(x, skip) of the concat skip connection [rows, 2D], activation dtype
+    uint8_t* mask1 = nullptr;          // key mask with the leading 1 of the time token
+    std::vector<float*> skips;         // depth / 2 saved streams
     int fallbacks = 0;             // calls repeated with fp32 storage so far (f5_plan_get_option "residual_fallbacks")
     unsigned sat_amax_bits = 0;    // what the last event saw: largest finite |element| (float bits) and whether a NaN was read
     bool sat_nan = false;
@@ -146,7 +157,11 @@ extern "C" int f5_model_create(const f5_dit_config* c, f5_model_t* out) {
     if (c->dim <= 0 || c->dim % 128 != 0 || c->dim > 2048) return f5_fail(F5_EINVAL, "dim=%d must be a multiple of 128 (<= 2048)", c->dim);
     if (c->depth <= 0 || c->heads <= 0 || c->ff_inner <= 0 || c->ff_inner % 32 != 0) return f5_fail(F5_EINVAL, "bad depth/heads/ff_inner");
     if (c->mel_dim <= 0 || c->mel_dim > MELP || c->mel_dim % 4 != 0) return f5_fail(F5_EINVAL, "mel_dim=%d unsupported", c->mel_dim);
-    if (c->text_dim <= 0 || c->text_dim % 32 != 0 || c->text_dim > 1024) return f5_fail(F5_EINVAL, "text_dim=%d must be a multiple of 32", c->text_dim);
+    if (c->backbone != F5_BACKBONE_DIT && c->backbone != F5_BACKBONE_UNETT) return f5_fail(F5_EINVAL, "bad backbone");
+    if (c->backbone == F5_BACKBONE_UNETT && (c->depth % 2 != 0 || c->skip_connect < F5_SKIP_CONCAT || c->skip_connect > F5_SKIP_NONE))
+        return f5_fail(F5_EINVAL, "UNetT: depth must be even (unett.py:120) and skip_connect one of F5_SKIP_*");
+    if (c->text_dim <= 0 || c->text_dim % 4 != 0 || c->text_dim > 1024 || (c->conv_layers > 0 && c->text_dim % 32 != 0))
+        return f5_fail(F5_EINVAL, "text_dim=%d must be a multiple of 4 (of 32 with ConvNeXt text blocks)", c->text_dim);
     if (c->text_num_embeds <= 0 || c->conv_layers < 0) return f5_fail(F5_EINVAL, "bad text config");
     if (c->precision != F5_PREC_BF16 && c->precision != F5_PREC_FP32) return f5_fail(F5_EINVAL, "bad precision");
     if (c->rope_layout != F5_ROPE_ADJACENT && c->rope_layout != F5_ROPE_HALF_SPLIT) return f5_fail(F5_EINVAL, "bad rope_layout");
@@ -154,7 +169,8 @@ extern "C" int f5_model_create(const f5_dit_config* c, f5_model_t* out) {
     m->cfg = *c;
     const int64_t D = c->dim, td = c->text_dim, inner = (int64_t)c->heads * 64, ff = c->ff_inner, mel = c->mel_dim;
     m->inner = (int)inner;
-    m->modrow = (int)(c->depth * 6 * D + 2 * D);
+    m->modrow = c->backbone == F5_BACKBONE_UNETT ? 0 : (int)(c->depth * 6 * D + 2 * D);
+    m->td_pad = (int)round_up(c->text_dim, 32);
     m->rope_heads = (c->pe_attn_head <= 0 || c->pe_attn_head > c->heads) ? c->heads : c->pe_attn_head;
     SlotMap& s = m->slots;
     add_slot(s, "time_embed.time_mlp.0.weight", {D, 256});
@@ -181,23 +197,43 @@ extern "C" int f5_model_create(const f5_dit_config* c, f5_model_t* out) {
         add_slot(s, "input_embed.conv_pos_embed.conv1d." + std::to_string(i) + ".weight", {D, D / 16, 31});
         add_slot(s, "input_embed.conv_pos_embed.conv1d." + std::to_string(i) + ".bias", {D});
     }
-    for (int i = 0; i < c->depth; ++i) {
-        const std::string p = "transformer_blocks." + std::to_string(i) + ".";
-        add_slot(s, p + "attn_norm.linear.weight", {6 * D, D});
-        add_slot(s, p + "attn_norm.linear.bias", {6 * D});
-        for (const char* nm : {"to_q", "to_k", "to_v"}) {
-            add_slot(s, p + "attn." + nm + ".weight", {inner, D});
-            add_slot(s, p + "attn." + nm + ".bias", {inner});
+    if (c->backbone == F5_BACKBONE_UNETT) {  // unett.py:139-175: layers.<i> = [skip_proj | None, attn_norm, attn, ff_norm, ff]
+        for (int i = 0; i < c->depth; ++i) {
+            const std::string p = "layers." + std::to_string(i) + ".";
+            if (i >= c->depth / 2 && c->skip_connect == F5_SKIP_CONCAT) add_slot(s, p + "0.weight", {D, 2 * D});
+            add_slot(s, p + "1.g", {D});
+            for (const char* nm : {"to_q", "to_k", "to_v"}) {
+                add_slot(s, p + "2." + nm + ".weight", {inner, D});
+                add_slot(s, p + "2." + nm + ".bias", {inner});
+            }
+            add_slot(s, p + "2.to_out.0.weight", {D, inner});
+            add_slot(s, p + "2.to_out.0.bias", {D});
+            add_slot(s, p + "3.g", {D});
+            add_slot(s, p + "4.ff.0.0.weight", {ff, D});
+            add_slot(s, p + "4.ff.0.0.bias", {ff});
+            add_slot(s, p + "4.ff.2.weight", {D, ff});
+            add_slot(s, p + "4.ff.2.bias", {D});
         }
-        add_slot(s, p + "attn.to_out.0.weight", {D, inner});
-        add_slot(s, p + "attn.to_out.0.bias", {D});
-        add_slot(s, p + "ff.ff.0.0.weight", {ff, D});
-        add_slot(s, p + "ff.ff.0.0.bias", {ff});
-        add_slot(s, p + "ff.ff.2.weight", {D, ff});
-        add_slot(s, p + "ff.ff.2.bias", {D});
+        add_slot(s, "norm_out.g", {D});
+    } else {
+        for (int i = 0; i < c->depth; ++i) {
+            const std::string p = "transformer_blocks." + std::to_string(i) + ".";
+            add_slot(s, p + "attn_norm.linear.weight", {6 * D, D});
+            add_slot(s, p + "attn_norm.linear.bias", {6 * D});
+            for (const char* nm : {"to_q", "to_k", "to_v"}) {
+                add_slot(s, p + "attn." + nm + ".weight", {inner, D});
+                add_slot(s, p + "attn." + nm + ".bias", {inner});
+            }
+            add_slot(s, p + "attn.to_out.0.weight", {D, inner});
+            add_slot(s, p + "attn.to_out.0.bias", {D});
+            add_slot(s, p + "ff.ff.0.0.weight", {ff, D});
+            add_slot(s, p + "ff.ff.0.0.bias", {ff});
+            add_slot(s, p + "ff.ff.2.weight", {D, ff});
+            add_slot(s, p + "ff.ff.2.bias", {D});
+        }
+        add_slot(s, "norm_out.linear.weight", {2 * D, D});
+        add_slot(s, "norm_out.linear.bias", {2 * D});
     }
-    add_slot(s, "norm_out.linear.weight", {2 * D, D});
-    add_slot(s, "norm_out.linear.bias", {2 * D});
     add_slot(s, "proj_out.weight", {mel, D});
     add_slot(s, "proj_out.bias", {mel});
     // x_transformers RotaryEmbedding(64).inv_freq (persistent buffer; optional in checkpoints)
@@ -246,7 +282,7 @@ extern "C" int f5_model_finalize(f5_model_t m) {
     F5_TRY(f5_upload_f32(A, H(m, "time_embed.time_mlp.2.weight").data(), D * D, &m->w_t2));
     F5_TRY(f5_upload_f32(A, H(m, "time_embed.time_mlp.2.bias").data(), D, &m->b_t2));
     // AdaLN linears of every block + the final one, concatenated (fp32)
-    {
+    if (c.backbone == F5_BACKBONE_DIT) {
         std::vector<float> w((size_t)m->modrow * D), b(m->modrow);
         for (int i = 0; i < c.depth; ++i) {
             const std::string p = "transformer_blocks." + std::to_string(i) + ".attn_norm.linear.";
@@ -296,7 +332,7 @@ extern "C" int f5_model_finalize(f5_model_t m) {
     // input projection split: columns [x | cond | text]  (dit.py:88,95 concat order)
     {
         const std::vector<float>& w = H(m, "input_embed.proj.weight");
-        const size_t kin = 2 * mel + td, kct = MELP + td;
+        const size_t kin = 2 * mel + td, kct = MELP + (size_t)m->td_pad;  // (text columns zero-padded to the GEMM's K granule)
         std::vector<float> wx(D * MELP, 0.f), wct(D * kct, 0.f);
         for (size_t n = 0; n < D; ++n) {
             for (size_t k = 0; k < mel; ++k) wx[n * MELP + k] = w[n * kin + k];
@@ -335,14 +371,16 @@ extern "C" int f5_model_finalize(f5_model_t m) {
     }
     // transformer blocks: fused QKV weight [3*inner, D]
     m->blocks.resize(c.depth);
+    const bool un = c.backbone == F5_BACKBONE_UNETT;
     for (int i = 0; i < c.depth; ++i) {
-        const std::string p = "transformer_blocks." + std::to_string(i) + ".";
+        const std::string p = (un ? "layers." : "transformer_blocks.") + std::to_string(i) + ".";
+        const std::string pa = p + (un ? "2." : "attn."), pf = p + (un ? "4." : "ff.");
         BlockW& b = m->blocks[i];
         std::vector<float> w(3 * inner * D), bias(3 * inner);
         const char* nm[3] = {"to_q", "to_k", "to_v"};
         for (int j = 0; j < 3; ++j) {
-            memcpy(&w[(size_t)j * inner * D], H(m, p + "attn." + nm[j] + ".weight").data(), inner * D * sizeof(float));
-            memcpy(&bias[(size_t)j * inner], H(m, p + "attn." + nm[j] + ".bias").data(), inner * sizeof(float));
+            memcpy(&w[(size_t)j * inner * D], H(m, pa + nm[j] + ".weight").data(), inner * D * sizeof(float));
+            memcpy(&bias[(size_t)j * inner], H(m, pa + nm[j] + ".bias").data(), inner * sizeof(float));
         }
         if (c.rope_layout == F5_ROPE_HALF_SPLIT) {
             // The kernels rotate ADJACENT feature pairs.  The half-split form turns (j, j + 32) with frequency j; QK^T is invariant under
@@ -364,13 +402,19 @@ extern "C" int f5_model_finalize(f5_model_t m) {
         }
         F5_TRY(f5_upload_t(A, P, w.data(), w.size(), &b.w_qkv));
         F5_TRY(f5_upload_f32(A, bias.data(), bias.size(), &b.b_qkv));
-        F5_TRY(f5_upload_t(A, P, H(m, p + "attn.to_out.0.weight").data(), D * inner, &b.w_o));
-        F5_TRY(f5_upload_f32(A, H(m, p + "attn.to_out.0.bias").data(), D, &b.b_o));
-        F5_TRY(f5_upload_t(A, P, H(m, p + "ff.ff.0.0.weight").data(), ff * D, &b.w_ff1));
-        F5_TRY(f5_upload_f32(A, H(m, p + "ff.ff.0.0.bias").data(), ff, &b.b_ff1));
-        F5_TRY(f5_upload_t(A, P, H(m, p + "ff.ff.2.weight").data(), D * ff, &b.w_ff2));
-        F5_TRY(f5_upload_f32(A, H(m, p + "ff.ff.2.bias").data(), D, &b.b_ff2));
+        F5_TRY(f5_upload_t(A, P, H(m, pa + "to_out.0.weight").data(), D * inner, &b.w_o));
+        F5_TRY(f5_upload_f32(A, H(m, pa + "to_out.0.bias").data(), D, &b.b_o));
+        F5_TRY(f5_upload_t(A, P, H(m, pf + "ff.0.0.weight").data(), ff * D, &b.w_ff1));
+        F5_TRY(f5_upload_f32(A, H(m, pf + "ff.0.0.bias").data(), ff, &b.b_ff1));
+        F5_TRY(f5_upload_t(A, P, H(m, pf + "ff.2.weight").data(), D * ff, &b.w_ff2));
+        F5_TRY(f5_upload_f32(A, H(m, pf + "ff.2.bias").data(), D, &b.b_ff2));
+        if (un) {
+            F5_TRY(f5_upload_f32(A, H(m, p + "1.g").data(), D, &b.g_attn));
+            F5_TRY(f5_upload_f32(A, H(m, p + "3.g").data(), D, &b.g_ff));
+            if (i >= c.depth / 2 && c.skip_connect == F5_SKIP_CONCAT) F5_TRY(f5_upload_t(A, P, H(m, p + "0.weight").data(), D * 2 * D, &b.w_skip));
+        }
     }
+    if (un) F5_TRY(f5_upload_f32(A, H(m, "norm_out.g").data(), D, &m->g_out));
     {
         // proj_out rows padded to MELP so the tuned kernel can run it too (rows >= mel are zero)
         std::vector<float> w((size_t)MELP * D, 0.f), b(MELP, 0.f);
@@ -408,7 +452,8 @@ extern "C" int f5_plan_create(f5_model_t m, int max_batch, int max_seq, int max_
     p->maxB = max_batch;
     p->maxN = max_seq;
     p->maxE = max_evals;
-    const size_t bn = (size_t)max_batch * max_seq;
+    const bool un = c.backbone == F5_BACKBONE_UNETT;
+    const size_t bn = (size_t)max_batch * (max_seq + (un ? 1 : 0));  // (UNetT: one time token per utterance rides in front of the frames)
     const size_t rows = (size_t)round_up(2 * bn, 256);  // CFG-doubled, padded to the tuned GEMM's tile height
     p->rows_cap = rows;
     DevArena& A = p->arena;
@@ -431,9 +476,9 @@ extern "C" int f5_plan_create(f5_model_t m, int max_batch, int max_seq, int max_
         if ((rc = A.alloc(&p->yA, rows * D * es))) break;
         if ((rc = A.alloc(&p->qkv, rows * 3 * inner * es))) break;
         if ((rc = A.alloc(&p->ffh, rows * ff * es))) break;
-        if ((rc = A.alloc(&p->abase, rows * (MELP + td) * es))) break;
+        if ((rc = A.alloc(&p->abase, rows * (MELP + (size_t)m->td_pad) * es))) break;
         if ((rc = A.alloc(&p->xin, (size_t)round_up(bn, 256) * MELP * es))) break;
-        if ((rc = A.alloc_t(&p->mod, modrows * m->modrow))) break;
+        if ((rc = A.alloc_t(&p->mod, modrows * (size_t)std::max(m->modrow, 1)))) break;
         if ((rc = A.alloc_t(&p->temb, modrows * D))) break;
         if ((rc = A.alloc_t(&p->thid, modrows * D))) break;
         if ((rc = A.alloc_t(&p->tsin, modrows * 256))) break;
@@ -454,15 +499,26 @@ extern "C" int f5_plan_create(f5_model_t m, int max_batch, int max_seq, int max_
         if ((rc = A.alloc_t(&p->lens_in, (size_t)max_batch))) break;
         if ((rc = A.alloc_t(&p->dur_in, (size_t)max_batch))) break;
         // RoPE table for positions < max_seq: angle = p * inv_freq_j in fp32, as x_transformers computes it
-        std::vector<float> rope((size_t)max_seq * 64);
-        for (int pos = 0; pos < max_seq; ++pos)
+        const int rope_n = max_seq + (un ? 1 : 0);
+        std::vector<float> rope((size_t)rope_n * 64);
+        for (int pos = 0; pos < rope_n; ++pos)
             for (int j = 0; j < 32; ++j) {
                 const float ang = (float)pos * m->inv_freq[j];
                 rope[((size_t)pos * 32 + j) * 2] = cosf(ang);
                 rope[((size_t)pos * 32 + j) * 2 + 1] = sinf(ang);
             }
         if ((rc = f5_upload_f32(A, rope.data(), rope.size(), &p->rope))) break;
-        p->rope_n = max_seq;
+        p->rope_n = rope_n;
+        if (un) {
+            if ((rc = A.alloc_t(&p->xin_res, rows * D))) break;
+            if ((rc = A.alloc_t(&p->vout_s, rows * MELP))) break;
+            if (c.skip_connect == F5_SKIP_CONCAT && (rc = A.alloc(&p->catT, rows * 2 * D * es))) break;
+            if ((rc = A.alloc_t(&p->mask1, 2 * bn))) break;
+            p->skips.assign(c.depth / 2, nullptr);
+            for (auto& sk : p->skips)
+                if ((rc = A.alloc_t(&sk, rows * D))) break;
+            if (rc) break;
+        }
         if ((rc = A.alloc_t(&p->sat_base, 1024))) break;  // the 8 flag words sit in the middle of a 4 KiB block of their own
         p->sat_flag = p->sat_base + 512;
         if (hipHostMalloc((void**)&p->sat_host, 32, hipHostMallocDefault) != hipSuccess) {
@@ -621,6 +677,7 @@ int g_sync_evals = 0;  // diagnostic knob ("sync_evals"): an eager sample() sync
 // fp16 residual storage for this plan's evaluations (bf16 mode without stage taps; the plan option overrides the process-wide knob)
 static bool plan_res_f16(const f5_plan_s* p) {
     const bool want = p->res_f16 < 0 ? g_res_f16 != 0 : p->res_f16 != 0;
+    if (p->m->cfg.backbone != F5_BACKBONE_DIT) return false;  // (UNetT keeps its stream in fp32)
     return want && p->taps.empty() && g_ln_defer && p->m->cfg.precision == F5_PREC_BF16 && p->xres16 && p->base16;
 }
 
@@ -659,8 +716,8 @@ static int compute_modulation(f5_plan_s* p, const float* tvals_dev, int n, hipSt
     F5_TRY(launch_gemv_rows(p->tsin, 256, n, m->w_t0, m->b_t0, D, 256, 0, 1, p->thid, D, st));  // Linear -> SiLU
     F5_TRY(launch_gemv_rows(p->thid, D, n, m->w_t2, m->b_t2, D, D, 0, 0, p->temb, D, st));      // Linear
     F5_TRY(tap_f32(p, "t_emb", p->temb, D, n, D, st));
-    // every AdaLN: Linear(SiLU(t_emb))  (modules.py:311,332)
-    F5_TRY(launch_gemv_rows(p->temb, D, n, m->w_adaln, m->b_adaln, m->modrow, D, 1, 0, p->mod, m->modrow, st));
+    // every AdaLN: Linear(SiLU(t_emb))  (modules.py:311,332); UNetT has none: its layers see the time as a token (unett.py:211-213)
+    if (m->modrow > 0) F5_TRY(launch_gemv_rows(p->temb, D, n, m->w_adaln, m->b_adaln, m->modrow, D, 1, 0, p->mod, m->modrow, st));
     return 0;
 }
 
@@ -696,7 +753,7 @@ static int compute_base(f5_plan_s* p, const float* cond, const int32_t* lens, co
                         hipStream_t st) {
     f5_model_s* m = p->m;
     const f5_dit_config& c = m->cfg;
-    const int D = c.dim, td = c.text_dim, P = c.precision, kct = MELP + td;
+    const int D = c.dim, td = c.text_dim, P = c.precision, kct = MELP + m->td_pad;  // (columns td .. td_pad stay zero: the arena zero-fills)
     const size_t es = f5_elem_size(P);
     void* ab = (char*)p->abase + row0 * kct * es;
     F5_TRY(launch_pack_base(P, cond, lens, te, nb, N, c.mel_dim, MELP, td, zero_cond, ab, kct, st));
@@ -867,6 +924,97 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
     return run_gemm(p, g, GEMM_DENSE, EPI_STORE_F32, st);
 }
 
+// one evaluation of the UNetT backbone (reference model/backbones/unett.py:185-253) over `nb` batch rows; temb = time embedding of batch row b at
+// temb + b * temb_bstride (stride 0: one time for all).  Result: p->vout [nb * N, MELP] f32 (the time token's row dropped, :246).
+// The stream is fp32 (`xres`, read-modify-write by the fp32 EPI_RESID epilogues); activations in the precision's dtype.
+static int unett_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, const float* temb, int temb_bstride, const uint8_t* mask, hipStream_t st) {
+    f5_model_s* m = p->m;
+    const f5_dit_config& c = m->cfg;
+    const int D = c.dim, P = c.precision, inner = m->inner, ff = c.ff_inner, S = N + 1, rows_in = nb * N, rows = nb * S;
+    const size_t es = f5_elem_size(P);
+    // InputEmbedding (unett.py:88-98): h = proj(cat(x, cond, text)); x = conv_pos_embed(h) + h
+    F5_TRY(launch_convert_pad(P, x, c.mel_dim, xrows, c.mel_dim, MELP, p->xin, MELP, st));
+    GemmParams g = gp_zero();
+    g.A = p->xin; g.lda = MELP; g.W = m->w_x; g.ldw = MELP; g.M = rows_in; g.N = D; g.K = MELP;
+    g.a_row_mod = xrows < rows_in ? xrows : 0;
+    g.addend = p->base; g.ldadd = D; g.out_t = p->hT; g.ldo = D; g.out_f = p->xin_res; g.ldof = D;
+    F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_ADD2, st));
+    for (int li = 0; li < 2; ++li) {
+        g = gp_zero();
+        g.A = li == 0 ? p->hT : p->cT; g.lda = D; g.W = m->w_conv[li]; g.M = rows_in; g.N = D; g.K = 31 * m->conv_win;
+        g.bias = m->b_conv[li]; g.act = ACT_MISH; g.rows_per_batch = N; g.conv_cg = m->conv_cg; g.conv_win = m->conv_win;
+        g.out_t = li == 0 ? p->cT : p->yT; g.ldo = D;
+        F5_TRY(run_gemm(p, g, GEMM_CONV31, li == 0 ? EPI_STORE_T : EPI_GATE_T, st));
+    }
+    // x = cat([t, x], dim=1); mask = pad(mask, (1, 0), 1)  (:211-214)
+    F5_TRY(launch_pack_time_token(P, p->xin_res, p->yT, temb, temb_bstride, nb, N, D, p->xres, st));
+    const uint8_t* mask1 = nullptr;
+    if (mask) {
+        F5_TRY(launch_pad_mask(mask, nb, N, p->mask1, st));
+        mask1 = p->mask1;
+    }
+    const int half = c.depth / 2;
+    for (int l = 0; l < c.depth; ++l) {
+        const BlockW& b = m->blocks[l];
+        if (l < half) {  // skips.append(x)  (:229-230)
+            F5_HIP(hipMemcpyAsync(p->skips[l], p->xres, (size_t)rows * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+        } else {         // skip = skips.pop()  (:232-238)
+            const float* skip = p->skips[c.depth - 1 - l];
+            if (c.skip_connect == F5_SKIP_CONCAT) {
+                F5_TRY(launch_convert_pad(P, p->xres, D, rows, D, D, p->catT, 2 * D, st));
+                F5_TRY(launch_convert_pad(P, skip, D, rows, D, D, (char*)p->catT + (size_t)D * es, 2 * D, st));
+                g = gp_zero();
+                g.A = p->catT; g.lda = 2 * D; g.W = b.w_skip; g.ldw = 2 * D; g.M = rows; g.N = D; g.K = 2 * D;
+                g.out_f = p->xres; g.ldof = D;
+                F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_STORE_F32, st));
+            } else if (c.skip_connect == F5_SKIP_ADD) {
+                F5_TRY(launch_add_f32(p->xres, skip, (size_t)rows * D, st));
+            }
+        }
+        // x = attn(attn_norm(x), rope, mask) + x  (:241)
+        F5_TRY(launch_rmsnorm(P, p->xres, D, rows, D, b.g_attn, p->hT, D, st));
+        g = gp_zero();
+        g.A = p->hT; g.lda = D; g.W = b.w_qkv; g.ldw = D; g.M = rows; g.N = 3 * inner; g.K = D;
+        g.bias = b.b_qkv; g.out_t = p->qkv; g.ldo = 3 * inner; g.rows_per_batch = S;
+        g.rope = p->rope; g.rope_inner = inner; g.rope_heads = m->rope_heads;
+        F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_ROPE_T, st));
+        {
+            int kind = 0;
+            if (p->attn_kernel != 0 && attention_fast_supported(P, S, c.heads)) kind = 1;
+            F5_TRY(launch_attention(P, kind, nb, S, c.heads, p->qkv, 3 * inner, mask1, p->cT, inner, st));
+        }
+        g = gp_zero();
+        g.A = p->cT; g.lda = inner; g.W = b.w_o; g.ldw = inner; g.M = rows; g.N = D; g.K = inner;
+        g.bias = b.b_o; g.out_f = p->xres; g.ldof = D; g.rows_per_batch = S; g.rowmask = mask1;  // masked query rows: attention output is 0 (modules.py:499-501)
+        F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_RESID, st));
+        // x = ff(ff_norm(x)) + x  (:242)
+        F5_TRY(launch_rmsnorm(P, p->xres, D, rows, D, b.g_ff, p->hT, D, st));
+        g = gp_zero();
+        g.A = p->hT; g.lda = D; g.W = b.w_ff1; g.ldw = D; g.M = rows; g.N = ff; g.K = D;
+        g.bias = b.b_ff1; g.act = ACT_GELU_TANH; g.out_t = p->ffh; g.ldo = ff;
+        F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_STORE_T, st));
+        g = gp_zero();
+        g.A = p->ffh; g.lda = ff; g.W = b.w_ff2; g.ldw = ff; g.M = rows; g.N = D; g.K = ff;
+        g.bias = b.b_ff2; g.out_f = p->xres; g.ldof = D; g.rows_per_batch = S;
+        F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_RESID, st));
+    }
+    // x = norm_out(x)[:, 1:, :]; proj_out  (:246-248)
+    F5_TRY(launch_rmsnorm(P, p->xres, D, rows, D, m->g_out, p->hT, D, st));
+    g = gp_zero();
+    g.A = p->hT; g.lda = D; g.W = m->w_out; g.ldw = D; g.M = rows; g.N = MELP; g.K = D;
+    g.bias = m->b_out; g.out_f = p->vout_s; g.ldof = MELP;
+    F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_STORE_F32, st));
+    return launch_drop_time_token(p->vout_s, nb, N, MELP, p->vout, st);
+}
+
+// one network evaluation of whichever backbone the model is (plug point A)
+static int net_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, int time_row, int per_batch_rows, const uint8_t* mask, hipStream_t st) {
+    f5_model_s* m = p->m;
+    if (m->cfg.backbone == F5_BACKBONE_UNETT)
+        return unett_eval(p, x, xrows, nb, N, p->temb + (size_t)time_row * m->cfg.dim, per_batch_rows ? m->cfg.dim : 0, mask, st);
+    return dit_eval(p, x, xrows, nb, N, p->mod + (size_t)time_row * m->modrow, per_batch_rows ? m->modrow : 0, mask, st);
+}
+
 static int check_plan_shape(f5_plan_s* p, int B, int N) {
     if (!p) return f5_fail(F5_EINVAL, "null plan");
     if (B <= 0 || N <= 0 || B > p->maxB || N > p->maxN || (size_t)B * N > (size_t)p->maxB * p->maxN)
@@ -890,7 +1038,7 @@ extern "C" int f5_dit_forward(f5_plan_t p, int B, int N, const float* x, const f
     p->mod_tv.clear();  // p->mod is overwritten with per-sample times
     F5_TRY(compute_modulation(p, time, B, st));
     F5_TRY(compute_base(p, cond, nullptr, text_embed, B, N, drop_audio_cond, 0, st));
-    F5_TRY(dit_eval(p, x, B * N, B, N, p->mod, m->modrow, mask, st));
+    F5_TRY(net_eval(p, x, B * N, B, N, 0, 1, mask, st));
     return launch_convert_back(F5_PREC_FP32, p->vout, MELP, B * N, m->cfg.mel_dim, out, m->cfg.mel_dim, st);
 }
 
@@ -933,12 +1081,12 @@ static int sample_body(f5_plan_s* p, const SampleArgs& a, hipStream_t st) {
         float* xn = p->traj + (size_t)(s + 1) * state;
         const float* vu = a.cfg_on ? p->vout + (size_t)bn * MELP : nullptr;
         if (a.method == F5_ODE_EULER) {
-            F5_TRY(dit_eval(p, xs, bn, nb, N, p->mod + (size_t)s * m->modrow, 0, mask, st));
+            F5_TRY(net_eval(p, xs, bn, nb, N, s, 0, mask, st));
             F5_TRY(launch_cfg_step(xs, p->vout, vu, MELP, bn, mel, a.cfg, p->coefs + s, xn, nullptr, st));
         } else {
-            F5_TRY(dit_eval(p, xs, bn, nb, N, p->mod + (size_t)(2 * s) * m->modrow, 0, mask, st));
+            F5_TRY(net_eval(p, xs, bn, nb, N, 2 * s, 0, mask, st));
             F5_TRY(launch_cfg_step(xs, p->vout, vu, MELP, bn, mel, a.cfg, p->coefs + 2 * s, p->xmid, nullptr, st));
-            F5_TRY(dit_eval(p, p->xmid, bn, nb, N, p->mod + (size_t)(2 * s + 1) * m->modrow, 0, mask, st));
+            F5_TRY(net_eval(p, p->xmid, bn, nb, N, 2 * s + 1, 0, mask, st));
             F5_TRY(launch_cfg_step(xs, p->vout, vu, MELP, bn, mel, a.cfg, p->coefs + 2 * s + 1, xn, nullptr, st));
         }
     }

@@ -1,1 +1,2 @@
 from .dit import DiT  # noqa: F401
+from .unett import UNetT  # noqa: F401

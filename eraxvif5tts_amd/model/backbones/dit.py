@@ -67,21 +67,34 @@ def _register(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer=False):
 
 
 class DiT(nn.Module):
+    BACKBONE = _lib.F5_BACKBONE_DIT
+
     def __init__(self, *, dim, depth=8, heads=8, dim_head=64, dropout=0.1, ff_mult=4, mel_dim=100, text_num_embeds=256,
                  text_dim=None, text_mask_padding=True, qk_norm=None, conv_layers=0, pe_attn_head=None,
                  long_skip_connection=False, checkpoint_activations=False, precision=None, rope_layout=None):
         super().__init__()
+        if long_skip_connection:
+            raise NotImplementedError("long_skip_connection is False in every shipped config and is not implemented")
+        self.checkpoint_activations = checkpoint_activations  # training-only knob; accepted and ignored
+        self._setup(dim=dim, depth=depth, heads=heads, dim_head=dim_head, ff_mult=ff_mult, mel_dim=mel_dim, text_num_embeds=text_num_embeds,
+                    text_dim=text_dim, text_mask_padding=text_mask_padding, qk_norm=qk_norm, conv_layers=conv_layers, pe_attn_head=pe_attn_head,
+                    precision=precision, rope_layout=rope_layout)
+
+    def _spec(self):
+        return _param_spec(self.dim, self.depth, self.heads, self.dim_head, self.ff_inner, self.mel_dim, self.text_num_embeds, self.text_dim,
+                           self.conv_layers)
+
+    def _setup(self, *, dim, depth, heads, dim_head, ff_mult, mel_dim, text_num_embeds, text_dim, text_mask_padding, qk_norm, conv_layers,
+               pe_attn_head, precision, rope_layout, skip_connect_type="concat"):
         if text_dim is None:
             text_dim = mel_dim
         if qk_norm is not None:
             raise NotImplementedError("qk_norm is null in every shipped config and is not implemented by the HIP kernels")
-        if long_skip_connection:
-            raise NotImplementedError("long_skip_connection is False in every shipped config and is not implemented")
         self.dim, self.depth, self.heads, self.dim_head = dim, depth, heads, dim_head
         self.ff_inner = int(dim * ff_mult)
         self.mel_dim, self.text_num_embeds, self.text_dim = mel_dim, text_num_embeds, text_dim
         self.text_mask_padding, self.conv_layers, self.pe_attn_head = bool(text_mask_padding), conv_layers, pe_attn_head
-        self.checkpoint_activations = checkpoint_activations  # training-only knob; accepted and ignored
+        self.skip_connect_type = skip_connect_type
         prec = precision or os.environ.get("F5HIP_PRECISION", "bf16")
         self.precision = {"bf16": _lib.F5_PREC_BF16, "fp32": _lib.F5_PREC_FP32}[prec]
         # x_transformers (dit.py:16,134) is not vendored in the reference tree: "adjacent" rotates feature pairs (2j, 2j+1), the form the
@@ -89,7 +102,7 @@ class DiT(nn.Module):
         layout = rope_layout or os.environ.get("F5HIP_ROPE_LAYOUT", "adjacent")
         self.rope_layout = {"adjacent": _lib.F5_ROPE_ADJACENT, "half_split": _lib.F5_ROPE_HALF_SPLIT}[layout]
 
-        for name, shape, init in _param_spec(dim, depth, heads, dim_head, self.ff_inner, mel_dim, text_num_embeds, text_dim, conv_layers):
+        for name, shape, init in self._spec():
             t = torch.empty(shape)
             if init == "zeros":
                 t.zero_()
@@ -156,7 +169,7 @@ class DiT(nn.Module):
                              mel_dim=self.mel_dim, text_num_embeds=self.text_num_embeds, text_dim=self.text_dim,
                              conv_layers=self.conv_layers, text_mask_padding=int(self.text_mask_padding),
                              pe_attn_head=self.pe_attn_head or 0, qk_norm=0, long_skip=0, precision=self.precision,
-                             rope_layout=self.rope_layout)
+                             rope_layout=self.rope_layout, backbone=self.BACKBONE, skip_connect=_lib.F5_SKIP[self.skip_connect_type])
         h = C.c_void_p()
         _lib.check(lib.f5_model_create(C.byref(cfg), C.byref(h)), "model_create")
         try:

@@ -75,7 +75,17 @@ typedef struct f5_dit_config {
     int32_t precision;         /* F5_PREC_* */
     int32_t rope_layout;       /* F5_ROPE_* : which feature pairs of a head one rotary frequency turns (x_transformers is not vendored
                                 * in the reference tree; the adjacent-pair form is the one the pinned >=1.31 releases publish) */
+    int32_t backbone;          /* F5_BACKBONE_*: which class of plug point A (0 = DiT, the default of a zero-initialised struct) */
+    int32_t skip_connect;      /* UNetT only: F5_SKIP_* (reference unett.py:118 skip_connect_type) */
 } f5_dit_config;
+
+/* backbones behind plug point A (reference infer/f5tts_wrapper.py:134: model_cls = f5_tts.model.<cfg.model.backbone>) */
+#define F5_BACKBONE_DIT 0   /* model/backbones/dit.py:103   (F5-TTS) */
+#define F5_BACKBONE_UNETT 1 /* model/backbones/unett.py:103 (E2-TTS: flat U-Net transformer; tensor names = UNetT.state_dict(): layers.<i>.{0.weight,
+                             * 1.g, 2.to_q|to_k|to_v|to_out.0.{weight,bias}, 3.g, 4.ff.0.0.*, 4.ff.2.*}, norm_out.g; depth must be even) */
+#define F5_SKIP_CONCAT 0 /* x = Linear(2 dim -> dim, no bias)(cat(x, skip)) in the second half of the layers (default) */
+#define F5_SKIP_ADD 1
+#define F5_SKIP_NONE 2
 
 /* rotary layouts of the q/k head features (dim_head = 64, 32 frequencies), reference model/modules.py:452-461 via x_transformers */
 #define F5_ROPE_ADJACENT 0  /* frequency j turns features (2j, 2j+1): rotate_half on '... (d r) -> ... d r', r = 2 (default) */

@@ -229,6 +229,95 @@ def dit_forward(W, cfg, x, cond, text, time, drop_audio_cond, drop_text, mask=No
     return out
 
 
+# ----------------------------------------------------------------------------- 8f-4: UNetT (flat U-Net transformer, the E2-TTS backbone)
+def rmsnorm_xt(x, g):
+    """x_transformers.RMSNorm as backbones/unett.py:17,146,156,175 uses it (third-party, unpinned): F.normalize(x, dim=-1) * sqrt(dim) * g."""
+    return F.normalize(x, dim=-1) * math.sqrt(x.shape[-1]) * g
+
+
+def unett_forward(W, cfg, x, cond, text, time, drop_audio_cond, drop_text, mask=None, text_embed=None):
+    """backbones/unett.py:185-253.  The time embedding is PREPENDED as one more token (:211-213: [b, n, d] -> [b, n+1, d]; the key mask gets a
+    leading 1), RoPE spans n+1 positions (:215); the first depth/2 layers push their input on a stack, the last depth/2 pop it and mix it in
+    (skip_connect_type "concat": Linear(2d -> d, no bias) on cat(x, skip); "add"; "none") BEFORE the layer's attention (:225-238); every layer is
+    x = attn(RMSNorm(x)) + x; x = ff(RMSNorm(x)) + x (:241-242, no AdaLN, no gates); output = proj_out(RMSNorm(x)[:, 1:]) (:246-248)."""
+    b, n, _ = x.shape
+    if time.ndim == 0:
+        time = time.repeat(b)
+    t_emb = timestep_embedding(W, time)
+    if text_embed is None:
+        text_embed = text_embedding(W, cfg, text, n, drop_text=drop_text)
+    h = input_embedding(W, x, cond, text_embed, drop_audio_cond=drop_audio_cond)
+    h = torch.cat([t_emb[:, None, :], h], dim=1)
+    if mask is not None:
+        mask = F.pad(mask, (1, 0), value=True)
+    ang = rope_angles(n + 1, cfg.get("dim_head", 64))
+    depth, sct = cfg["depth"], cfg.get("skip_connect_type", "concat")
+    skips = []
+    for i in range(depth):
+        pre = f"layers.{i}."
+        if i < depth // 2:
+            skips.append(h)
+        else:
+            skip = skips.pop()
+            if sct == "concat":
+                h = _lin(torch.cat([h, skip], dim=-1), W[pre + "0.weight"])
+            elif sct == "add":
+                h = h + skip
+        h = attention(W, pre + "2.", cfg, rmsnorm_xt(h, W[pre + "1.g"]), mask, ang) + h
+        n2 = rmsnorm_xt(h, W[pre + "3.g"])
+        h = _lin(gelu_tanh(_lin(n2, W[pre + "4.ff.0.0.weight"], W[pre + "4.ff.0.0.bias"])), W[pre + "4.ff.2.weight"], W[pre + "4.ff.2.bias"]) + h
+    assert not skips
+    h = rmsnorm_xt(h, W["norm_out.g"])[:, 1:, :]
+    return _lin(h, W["proj_out.weight"], W["proj_out.bias"])
+
+
+def unett_param_shapes(cfg, vocab_size, mel_dim=100):
+    """Names/shapes of the reference UNetT.state_dict() (unett.py:104-183) for an arch dict (rotary_embed.inv_freq excluded)."""
+    D, L = cfg["dim"], cfg["depth"]
+    td = cfg.get("text_dim") or mel_dim
+    inner, ff = cfg["heads"] * cfg.get("dim_head", 64), int(D * cfg.get("ff_mult", 4))
+    sh = {"time_embed.time_mlp.0.weight": (D, 256), "time_embed.time_mlp.0.bias": (D,), "time_embed.time_mlp.2.weight": (D, D),
+          "time_embed.time_mlp.2.bias": (D,), "text_embed.text_embed.weight": (vocab_size + 1, td)}
+    for i in range(cfg.get("conv_layers", 0)):
+        p = f"text_embed.text_blocks.{i}."
+        sh.update({p + "dwconv.weight": (td, 1, 7), p + "dwconv.bias": (td,), p + "norm.weight": (td,), p + "norm.bias": (td,),
+                   p + "pwconv1.weight": (2 * td, td), p + "pwconv1.bias": (2 * td,), p + "grn.gamma": (1, 1, 2 * td), p + "grn.beta": (1, 1, 2 * td),
+                   p + "pwconv2.weight": (td, 2 * td), p + "pwconv2.bias": (td,)})
+    sh.update({"input_embed.proj.weight": (D, 2 * mel_dim + td), "input_embed.proj.bias": (D,)})
+    for i in (0, 2):
+        sh.update({f"input_embed.conv_pos_embed.conv1d.{i}.weight": (D, D // 16, 31), f"input_embed.conv_pos_embed.conv1d.{i}.bias": (D,)})
+    for i in range(L):
+        p = f"layers.{i}."
+        if i >= L // 2 and cfg.get("skip_connect_type", "concat") == "concat":
+            sh[p + "0.weight"] = (D, 2 * D)
+        sh.update({p + "1.g": (D,), p + "3.g": (D,)})
+        for nm in ("to_q", "to_k", "to_v"):
+            sh.update({p + f"2.{nm}.weight": (inner, D), p + f"2.{nm}.bias": (inner,)})
+        sh.update({p + "2.to_out.0.weight": (D, inner), p + "2.to_out.0.bias": (D,), p + "4.ff.0.0.weight": (ff, D), p + "4.ff.0.0.bias": (ff,),
+                   p + "4.ff.2.weight": (D, ff), p + "4.ff.2.bias": (D,)})
+    sh.update({"norm_out.g": (D,), "proj_out.weight": (mel_dim, D), "proj_out.bias": (mel_dim,)})
+    return sh
+
+
+def random_unett_weights(cfg, vocab_size, seed=0, mel_dim=100):
+    """Deterministic (CPU generator) random UNetT weights: N(0, 1/fan_in) matrices, small biases, norm gains around 1."""
+    g = torch.Generator().manual_seed(seed)
+    W = {}
+    for name, shape in unett_param_shapes(cfg, vocab_size, mel_dim).items():
+        if name.endswith(".g") or name.endswith("norm.weight"):
+            W[name] = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif name.endswith("text_embed.weight"):
+            W[name] = torch.randn(shape, generator=g)
+        elif len(shape) == 1 or name.endswith("grn.gamma") or name.endswith("grn.beta"):
+            W[name] = 0.05 * torch.randn(shape, generator=g)
+        else:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            W[name] = torch.randn(shape, generator=g) / math.sqrt(fan_in)
+    return W
+
+
 # ----------------------------------------------------------------------------- a4-a8, a21: sampler
 def lens_to_mask(lens, length=None):
     """utils.py:42-47."""
@@ -276,11 +365,13 @@ def sample(W, cfg, cond, text, duration, *, lens=None, steps=32, cfg_strength=1.
     te_c = text_embedding(W, cfg, text, N, drop_text=False)
     te_u = text_embedding(W, cfg, text, N, drop_text=True)
 
+    fwd = unett_forward if cfg.get("backbone") == "UNetT" else dit_forward  # plug point A: cfm.py only calls transformer(...)
+
     def fn(t, x):
-        pred = dit_forward(W, cfg, x, step_cond, text, t, False, False, mask=mask, text_embed=te_c)
+        pred = fwd(W, cfg, x, step_cond, text, t, False, False, mask=mask, text_embed=te_c)
         if cfg_strength < 1e-5:
             return pred
-        null = dit_forward(W, cfg, x, step_cond, text, t, True, True, mask=mask, text_embed=te_u)
+        null = fwd(W, cfg, x, step_cond, text, t, True, True, mask=mask, text_embed=te_u)
         return pred + (pred - null) * cfg_strength
 
     t_start = 0.0

@@ -70,6 +70,22 @@ def apply_rotary_pos_emb(t, freqs, scale=1):
     return torch.cat((t, t_unrotated), dim=-1).type(orig_dtype)
 
 
+class RMSNorm(torch.nn.Module):
+    """x_transformers.RMSNorm (imported by backbones/unett.py:17; third-party, restated as published for the pinned >= 1.31 releases:
+    ``F.normalize(x, dim=-1) * dim ** 0.5 * g`` with a learned per-channel gain ``g`` initialised to 1).  Parity at this boundary is unpinned."""
+
+    def __init__(self, dim, unit_offset=False):
+        super().__init__()
+        self.unit_offset = unit_offset
+        self.scale = dim ** 0.5
+        self.g = torch.nn.Parameter(torch.zeros(dim))
+        torch.nn.init.constant_(self.g, 1.0 - float(unit_offset))
+
+    def forward(self, x):
+        gamma = self.g + float(self.unit_offset)
+        return torch.nn.functional.normalize(x, dim=-1) * self.scale * gamma
+
+
 def odeint(func, y0, t, *, method="euler", **_unused):
     """torchdiffeq fixed-grid solvers on the caller's grid: returns the stacked states at every t."""
     ys = [y0]
@@ -114,6 +130,7 @@ def load_reference():
     xtx.RotaryEmbedding = RotaryEmbedding
     xtx.apply_rotary_pos_emb = apply_rotary_pos_emb
     xt.x_transformers = xtx
+    xt.RMSNorm = RMSNorm
     td = _shell("torchdiffeq")
     td.odeint = odeint
     for pkg, path in (("f5_tts", f"{REF_ROOT}/f5_tts"), ("f5_tts.model", f"{REF_ROOT}/f5_tts/model"),
@@ -125,6 +142,12 @@ def load_reference():
     dit = importlib.import_module("f5_tts.model.backbones.dit")
     cfm = importlib.import_module("f5_tts.model.cfm")
     return modules, dit, cfm
+
+
+def load_unett():
+    """the reference's own backbones/unett.py (UNetT: the E2-TTS backbone, plug point A of SURVEY 8f-4), imported by path after load_reference()."""
+    load_reference()
+    return importlib.import_module("f5_tts.model.backbones.unett")
 
 
 def force_no_attn_dropout(modules):

