@@ -318,6 +318,146 @@ def random_unett_weights(cfg, vocab_size, seed=0, mel_dim=100):
     return W
 
 
+# ----------------------------------------------------------------------------- 8f-4: MMDiT (joint text / audio attention, SD3-style blocks)
+def mmdit_text_embedding(W, cfg, text, drop_text=False):
+    """backbones/mmdit.py:30-61: ids + 1 (0 = filler), NOT padded to the frame count; + sinusoidal table (1024 positions, index clamped
+    there, modules.py:210-219); filler rows (decided before drop_text zeroes the ids) are zeroed when text_mask_padding."""
+    ids = text + 1
+    filler = ids == 0
+    if drop_text:
+        ids = torch.zeros_like(ids)
+    x = W["text_embed.text_embed.weight"][ids]
+    pos = torch.arange(ids.shape[1]).clamp(max=1023)
+    x = x + text_pos_table(x.shape[-1], 1024)[pos][None]
+    if cfg.get("text_mask_padding", True):
+        x = x.masked_fill(filler[..., None], 0.0)
+    return x
+
+
+def _ada6(W, pre, t_emb):
+    return _lin(silu(t_emb), W[pre + "linear.weight"], W[pre + "linear.bias"]).chunk(6, dim=1)
+
+
+def _ff(W, pre, x):
+    return _lin(gelu_tanh(_lin(x, W[pre + "ff.0.0.weight"], W[pre + "ff.0.0.bias"])), W[pre + "ff.2.weight"], W[pre + "ff.2.bias"])
+
+
+def joint_attention(W, pre, cfg, x, c, mask, ang_x, ang_c, context_pre_only):
+    """modules.py:509-606 (JointAttnProcessor, dropout_p forced to 0): x and c have their own q/k/v projections; RoPE is applied to each
+    stream with its own positions 0.. (all heads); queries / keys / values are concatenated [x | c] along the sequence, the key mask is the
+    frame mask padded with True over the text; outputs are split back, to_out / to_out_c applied, padded x rows zeroed."""
+    b, n, _ = x.shape
+    nt = c.shape[1]
+    h, dh = cfg["heads"], cfg.get("dim_head", 64)
+    hs = cfg.get("rope_layout", "adjacent") == "half_split"
+
+    def proj(t, sfx, ang):
+        q = _lin(t, W[pre + f"to_q{sfx}.weight"], W[pre + f"to_q{sfx}.bias"]).view(b, -1, h, dh).transpose(1, 2)
+        k = _lin(t, W[pre + f"to_k{sfx}.weight"], W[pre + f"to_k{sfx}.bias"]).view(b, -1, h, dh).transpose(1, 2)
+        v = _lin(t, W[pre + f"to_v{sfx}.weight"], W[pre + f"to_v{sfx}.bias"]).view(b, -1, h, dh).transpose(1, 2)
+        return apply_rope(q, ang, hs), apply_rope(k, ang, hs), v
+
+    qx, kx, vx = proj(x, "", ang_x)
+    qc, kc, vc = proj(c, "_c", ang_c)
+    q, k, v = torch.cat([qx, qc], dim=2), torch.cat([kx, kc], dim=2), torch.cat([vx, vc], dim=2)
+    s = torch.einsum("bhid,bhjd->bhij", q, k) / math.sqrt(dh)
+    if mask is not None:
+        km = F.pad(mask, (0, nt), value=True)
+        s = s.masked_fill(~km[:, None, None, :], float("-inf"))
+    o = torch.einsum("bhij,bhjd->bhid", torch.softmax(s, dim=-1), v).transpose(1, 2).reshape(b, n + nt, h * dh)
+    ox, oc = o[:, :n], o[:, n:]
+    ox = _lin(ox, W[pre + "to_out.0.weight"], W[pre + "to_out.0.bias"])
+    oc = None if context_pre_only else _lin(oc, W[pre + "to_out_c.weight"], W[pre + "to_out_c.bias"])
+    if mask is not None:
+        ox = ox.masked_fill(~mask[..., None], 0.0)
+    return ox, oc
+
+
+def mmdit_forward(W, cfg, x, cond, text, time, drop_audio_cond, drop_text, mask=None, text_embed=None):
+    """backbones/mmdit.py:146-190 + MMDiTBlock (modules.py:646-707).  c = text embedding [b, nt, d]; x = Linear(cat(x, cond)) + its position
+    conv (:72-79).  Every block: AdaLN of both streams from t, joint attention, gated residual + gated FF on both; the LAST block is
+    context_pre_only (c only feeds the attention: AdaLayerNorm_Final (scale, shift), no to_out_c, no FF)."""
+    b, n, _ = x.shape
+    if time.ndim == 0:
+        time = time.repeat(b)
+    t_emb = timestep_embedding(W, time)
+    c = mmdit_text_embedding(W, cfg, text, drop_text=drop_text) if text_embed is None else text_embed
+    if drop_audio_cond:
+        cond = torch.zeros_like(cond)
+    h = _lin(torch.cat([x, cond], dim=-1), W["audio_embed.linear.weight"], W["audio_embed.linear.bias"])
+    y = h.transpose(1, 2)
+    for i in (0, 2):
+        y = mish(F.conv1d(y, W[f"audio_embed.conv_pos_embed.conv1d.{i}.weight"], W[f"audio_embed.conv_pos_embed.conv1d.{i}.bias"], padding=15, groups=16))
+    h = y.transpose(1, 2) + h
+    dh = cfg.get("dim_head", 64)
+    ang_x, ang_c = rope_angles(n, dh), rope_angles(c.shape[1], dh)
+    depth = cfg["depth"]
+    for i in range(depth):
+        pre = f"transformer_blocks.{i}."
+        last = i == depth - 1
+        if last:
+            sc, sh = _lin(silu(t_emb), W[pre + "attn_norm_c.linear.weight"], W[pre + "attn_norm_c.linear.bias"]).chunk(2, dim=1)
+            norm_c = _layernorm(c) * (1 + sc)[:, None] + sh[:, None]
+        else:
+            c_sh_a, c_sc_a, c_g_a, c_sh_m, c_sc_m, c_g_m = _ada6(W, pre + "attn_norm_c.", t_emb)
+            norm_c = _layernorm(c) * (1 + c_sc_a[:, None]) + c_sh_a[:, None]
+        x_sh_a, x_sc_a, x_g_a, x_sh_m, x_sc_m, x_g_m = _ada6(W, pre + "attn_norm_x.", t_emb)
+        norm_x = _layernorm(h) * (1 + x_sc_a[:, None]) + x_sh_a[:, None]
+        ax, ac = joint_attention(W, pre + "attn.", cfg, norm_x, norm_c, mask, ang_x, ang_c, last)
+        if last:
+            c = None
+        else:
+            c = c + c_g_a[:, None] * ac
+            c = c + c_g_m[:, None] * _ff(W, pre + "ff_c.", _layernorm(c) * (1 + c_sc_m[:, None]) + c_sh_m[:, None])
+        h = h + x_g_a[:, None] * ax
+        h = h + x_g_m[:, None] * _ff(W, pre + "ff_x.", _layernorm(h) * (1 + x_sc_m[:, None]) + x_sh_m[:, None])
+    scale, shift = _lin(silu(t_emb), W["norm_out.linear.weight"], W["norm_out.linear.bias"]).chunk(2, dim=1)
+    h = _layernorm(h) * (1 + scale)[:, None] + shift[:, None]
+    return _lin(h, W["proj_out.weight"], W["proj_out.bias"])
+
+
+def mmdit_param_shapes(cfg, vocab_size, mel_dim=100):
+    """Names/shapes of the reference MMDiT.state_dict() (mmdit.py:85-130) for an arch dict (rotary_embed.inv_freq excluded)."""
+    D, L = cfg["dim"], cfg["depth"]
+    inner, ff = cfg["heads"] * cfg.get("dim_head", 64), int(D * cfg.get("ff_mult", 4))
+    sh = {"time_embed.time_mlp.0.weight": (D, 256), "time_embed.time_mlp.0.bias": (D,), "time_embed.time_mlp.2.weight": (D, D),
+          "time_embed.time_mlp.2.bias": (D,), "text_embed.text_embed.weight": (vocab_size + 1, D),
+          "audio_embed.linear.weight": (D, 2 * mel_dim), "audio_embed.linear.bias": (D,)}
+    for i in (0, 2):
+        sh.update({f"audio_embed.conv_pos_embed.conv1d.{i}.weight": (D, D // 16, 31), f"audio_embed.conv_pos_embed.conv1d.{i}.bias": (D,)})
+    for i in range(L):
+        p, last = f"transformer_blocks.{i}.", i == L - 1
+        sh.update({p + "attn_norm_c.linear.weight": ((2 if last else 6) * D, D), p + "attn_norm_c.linear.bias": ((2 if last else 6) * D,),
+                   p + "attn_norm_x.linear.weight": (6 * D, D), p + "attn_norm_x.linear.bias": (6 * D,)})
+        for nm in ("to_q", "to_k", "to_v", "to_q_c", "to_k_c", "to_v_c"):
+            sh.update({p + f"attn.{nm}.weight": (inner, D), p + f"attn.{nm}.bias": (inner,)})
+        sh.update({p + "attn.to_out.0.weight": (D, inner), p + "attn.to_out.0.bias": (D,)})
+        for s in (("x",) if last else ("c", "x")):
+            sh.update({p + f"ff_{s}.ff.0.0.weight": (ff, D), p + f"ff_{s}.ff.0.0.bias": (ff,), p + f"ff_{s}.ff.2.weight": (D, ff), p + f"ff_{s}.ff.2.bias": (D,)})
+        if not last:
+            sh.update({p + "attn.to_out_c.weight": (D, inner), p + "attn.to_out_c.bias": (D,)})
+    sh.update({"norm_out.linear.weight": (2 * D, D), "norm_out.linear.bias": (2 * D,), "proj_out.weight": (mel_dim, D), "proj_out.bias": (mel_dim,)})
+    return sh
+
+
+def random_mmdit_weights(cfg, vocab_size, seed=0, mel_dim=100):
+    """Deterministic (CPU generator) random MMDiT weights: N(0, 1/fan_in) matrices, small biases (AdaLN / output layers live, unlike the
+    reference's zero init)."""
+    g = torch.Generator().manual_seed(seed)
+    W = {}
+    for name, shape in mmdit_param_shapes(cfg, vocab_size, mel_dim).items():
+        if name.endswith("text_embed.weight"):
+            W[name] = torch.randn(shape, generator=g)
+        elif len(shape) == 1:
+            W[name] = 0.05 * torch.randn(shape, generator=g)
+        else:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            W[name] = torch.randn(shape, generator=g) / math.sqrt(fan_in)
+    return W
+
+
 # ----------------------------------------------------------------------------- a4-a8, a21: sampler
 def lens_to_mask(lens, length=None):
     """utils.py:42-47."""
@@ -362,10 +502,13 @@ def sample(W, cfg, cond, text, duration, *, lens=None, steps=32, cfg_strength=1.
             rows.append(F.pad(torch.randn(d, nmel), (0, 0, 0, N - d)))
         y0 = torch.stack(rows)
 
-    te_c = text_embedding(W, cfg, text, N, drop_text=False)
-    te_u = text_embedding(W, cfg, text, N, drop_text=True)
-
-    fwd = unett_forward if cfg.get("backbone") == "UNetT" else dit_forward  # plug point A: cfm.py only calls transformer(...)
+    fwd = {"UNetT": unett_forward, "MMDiT": mmdit_forward}.get(cfg.get("backbone"), dit_forward)  # plug point A: cfm.py only calls transformer(...)
+    if cfg.get("backbone") == "MMDiT":
+        te_c = mmdit_text_embedding(W, cfg, text, drop_text=False)
+        te_u = mmdit_text_embedding(W, cfg, text, drop_text=True)
+    else:
+        te_c = text_embedding(W, cfg, text, N, drop_text=False)
+        te_u = text_embedding(W, cfg, text, N, drop_text=True)
 
     def fn(t, x):
         pred = fwd(W, cfg, x, step_cond, text, t, False, False, mask=mask, text_embed=te_c)

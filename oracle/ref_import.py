@@ -150,6 +150,12 @@ def load_unett():
     return importlib.import_module("f5_tts.model.backbones.unett")
 
 
+def load_mmdit():
+    """the reference's own backbones/mmdit.py (MMDiT, plug point A of SURVEY 8f-4), imported by path after load_reference()."""
+    load_reference()
+    return importlib.import_module("f5_tts.model.backbones.mmdit")
+
+
 def force_no_attn_dropout(modules):
     """Deterministic oracle: dropout_p of modules.py:490 forced to 0.0 (no edit to reference files)."""
     real = torch.nn.functional.scaled_dot_product_attention

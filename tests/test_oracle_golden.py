@@ -131,6 +131,45 @@ def test_true_size_e2tts_forward():
         assert rel_l2(out, z[key]) < 5e-5, key
 
 
+def _mmdit_case(z, tag):
+    import ast
+    arch = ast.literal_eval(str(z[f"{tag}.arch"]))
+    W = cpu_ref.random_mmdit_weights(arch, int(z[f"{tag}.vocab"]), seed=int(z[f"{tag}.seed"]))
+    return arch, W
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_mmdit_forward_and_sample_match_reference(tag):
+    """the oracle's restatement of the reference's MMDiT (backbones/mmdit.py:146-190, MMDiTBlock / JointAttnProcessor
+    modules.py:509-707: text stream of its own length, joint attention over [frames | text], context_pre_only last block) -- one forward
+    of both CFG branches with a key mask, CFM.sample driving it at B = 2 (mask) and B = 1 (no mask, midpoint) -- against vectors the
+    reference's own mmdit.py + cfm.py produced."""
+    z = load_golden("tiny_mmdit")
+    arch, W = _mmdit_case(z, tag)
+    g = lambda k: torch.from_numpy(z[f"{tag}.{k}"])
+    for drop, key in ((False, "out_c"), (True, "out_u")):
+        out = cpu_ref.mmdit_forward(W, arch, g("x"), g("cond"), g("text"), g("t"), drop, drop, mask=g("mask"))
+        assert rel_l2(out, z[f"{tag}.{key}"]) < 2e-5, key
+    cfg = dict(arch, backbone="MMDiT")
+    out, traj = cpu_ref.sample(W, cfg, g("cond")[:, :16], g("text"), g("duration"), lens=g("lens"), steps=4, cfg_strength=2.0,
+                               sway_sampling_coef=-1.0, seed=5)
+    assert rel_l2(traj, z[f"{tag}.sample_traj"]) < 2e-5 and rel_l2(out, z[f"{tag}.sample_out"]) < 2e-5
+    out, traj = cpu_ref.sample(W, cfg, g("cond")[:1, :16], g("text")[:1], 36, lens=g("lens")[:1], steps=3, cfg_strength=1.5, seed=9, method="midpoint")
+    assert rel_l2(traj, z[f"{tag}.b1_traj"]) < 2e-5 and rel_l2(out, z[f"{tag}.b1_out"]) < 2e-5
+
+
+def test_mmdit_forward_at_the_quoted_size():
+    """MMDiT at the size the reference quotes for it (scripts/count_params_gflops.py:18: dim 512, depth 16, heads 16, ff_mult 2): weights
+    regenerated from the seed on this machine."""
+    z = load_golden("mmdit_fwd")
+    cfg = dict(dim=512, depth=16, heads=16, ff_mult=2, text_mask_padding=True)
+    W = cpu_ref.random_mmdit_weights(cfg, int(z["vocab"]), seed=int(z["seed"]))
+    for drop, key in ((False, "out_c"), (True, "out_u")):
+        out = cpu_ref.mmdit_forward(W, cfg, torch.from_numpy(z["x"]), torch.from_numpy(z["cond"]), torch.from_numpy(z["text"]),
+                                    torch.from_numpy(z["t"]), drop, drop, mask=torch.from_numpy(z["mask"]))
+        assert rel_l2(out, z[key]) < 5e-5, key
+
+
 def test_time_grid_sway():
     t = cpu_ref.time_grid(32, -1.0)
     ref = 1 - torch.cos(torch.pi / 2 * torch.linspace(0, 1, 33))
