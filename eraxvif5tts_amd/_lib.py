@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libf5hip.so")
 F5_PREC_BF16, F5_PREC_FP32 = 0, 1
 F5_ODE_EULER, F5_ODE_MIDPOINT = 0, 1
 F5_ROPE_ADJACENT, F5_ROPE_HALF_SPLIT = 0, 1
-F5_BACKBONE_DIT, F5_BACKBONE_UNETT = 0, 1
+F5_BACKBONE_DIT, F5_BACKBONE_UNETT, F5_BACKBONE_MMDIT = 0, 1, 2
 F5_SKIP = {"concat": 0, "add": 1, "none": 2}
 SITES = ("qkv", "attention", "attn_out", "ff1", "ff2", "ln1", "ln2", "conv31", "input_proj")  # F5_SITE_* order
 ACT = {"none": 0, "gelu_tanh": 1, "gelu_erf": 2, "mish": 3}
@@ -58,6 +58,7 @@ _PROTOS = {
     "f5_sample_finish": (_I, [_P, _P]),
     "f5_text_embed": (_I, [_P, _I, _I, _P, _I, _I, _P, _P]),
     "f5_dit_forward": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
+    "f5_mmdit_forward": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "f5_plan_timing_begin": (_I, [_P, _I]),
     "f5_plan_timing_end": (_I, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int), _P]),
     "f5_plan_timing_site": (_I, [_P, _I, C.POINTER(C.c_float), C.POINTER(C.c_int)]),

@@ -447,6 +447,37 @@ int launch_drop_time_token(const float* src, int B, int N, int cols, float* dst,
     F5_LAUNCH_CHECK();
     return 0;
 }
+// ---- MMDiT (reference model/backbones/mmdit.py, JointAttnProcessor modules.py:509-606)
+// `nb` segments of seg_bytes each (multiple of 16, 16-byte aligned) from src + b * src_bstride to dst + b * dst_bstride: the x / text rows of
+// every utterance into (or out of) the joint [frames | text] sequence the attention kernel reads
+__global__ __launch_bounds__(256) void copy_segments_kernel(const uint4* __restrict__ src, size_t src_bstride, uint4* __restrict__ dst, size_t dst_bstride,
+                                                            size_t seg_vec) {
+    const uint4* s = src + (size_t)blockIdx.y * src_bstride;
+    uint4* d = dst + (size_t)blockIdx.y * dst_bstride;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < seg_vec; i += (size_t)gridDim.x * 256) d[i] = s[i];
+}
+int launch_copy_segments(const void* src, size_t src_bstride_bytes, void* dst, size_t dst_bstride_bytes, size_t seg_bytes, int nb, hipStream_t stream) {
+    if (nb <= 0 || seg_bytes == 0) return 0;
+    if ((seg_bytes | src_bstride_bytes | dst_bstride_bytes | (size_t)(uintptr_t)src | (size_t)(uintptr_t)dst) & 15)
+        return f5_fail(F5_EINVAL, "copy_segments: sizes and addresses must be multiples of 16 bytes");
+    const size_t vec = seg_bytes / 16;
+    const unsigned gx = (unsigned)std::min<size_t>((vec + 255) / 256, 4096);
+    hipLaunchKernelGGL(copy_segments_kernel, dim3(gx, nb), dim3(256), 0, stream, (const uint4*)src, src_bstride_bytes / 16, (uint4*)dst, dst_bstride_bytes / 16, vec);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+// modules.py:573: attn_mask = F.pad(mask, (0, nt), value=True) -- every text key is visible
+__global__ __launch_bounds__(256) void joint_mask_kernel(const uint8_t* __restrict__ mask, int B, int N, int nt, uint8_t* __restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x, S = N + nt;
+    if (i >= B * S) return;
+    const int b = i / S, sidx = i - b * S;
+    dst[i] = sidx < N ? mask[(size_t)b * N + sidx] : (uint8_t)1;
+}
+int launch_joint_mask(const uint8_t* mask, int B, int N, int nt, uint8_t* dst, hipStream_t stream) {
+    hipLaunchKernelGGL(joint_mask_kernel, dim3(cdiv(B * (N + nt), 256)), dim3(256), 0, stream, mask, B, N, nt, dst);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
 // x += y (skip_connect_type "add", unett.py:237-238); n % 4 == 0
 __global__ __launch_bounds__(256) void add_f32_kernel(float* __restrict__ x, const float* __restrict__ y, size_t nvec) {
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
@@ -604,25 +635,25 @@ int launch_grn(int precision, void* h, int B, int N, int C, const float* gamma, 
 
 // ----------------------------------------------------------------------------- text embedding gather (dit.py:49-68)
 __global__ __launch_bounds__(256) void text_gather_kernel(const int32_t* __restrict__ text, int nt, int B, int N, int td,
-                                                          const float* __restrict__ table, const float* __restrict__ pos_table, int drop_text,
-                                                          float* __restrict__ out, uint8_t* __restrict__ filler) {
+                                                          const float* __restrict__ table, const float* __restrict__ pos_table, int pos_rows,
+                                                          int drop_text, float* __restrict__ out, uint8_t* __restrict__ filler) {
     const int row = blockIdx.x;  // b * N + p
     const int b = row / N, p = row % N;
     int tok = 0;
     if (p < nt) tok = text[(size_t)b * nt + p] + 1;  // +1: 0 is the filler token; batch padding -1 -> 0
     if (threadIdx.x == 0 && filler) filler[row] = tok == 0;
     if (drop_text) tok = 0;
-    const int pp = p < 4096 ? p : 4095;  // get_pos_embed_indices clamps at precompute_max_pos (modules.py:218)
+    const int pp = p < pos_rows ? p : pos_rows - 1;  // get_pos_embed_indices clamps at precompute_max_pos (modules.py:218; 4096 dit.py:41, 1024 mmdit.py:37)
     for (int c = threadIdx.x; c < td; c += 256) {
         float v = table[(size_t)tok * td + c];
         if (pos_table) v += pos_table[(size_t)pp * td + c];
         out[(size_t)row * td + c] = v;
     }
 }
-int launch_text_gather(const int32_t* text, int nt, int B, int N, int td, const float* table, const float* pos_table, int drop_text,
+int launch_text_gather(const int32_t* text, int nt, int B, int N, int td, const float* table, const float* pos_table, int pos_rows, int drop_text,
                        float* out, uint8_t* filler, hipStream_t stream) {
     if (B * N <= 0) return 0;
-    hipLaunchKernelGGL(text_gather_kernel, dim3(B * N), dim3(256), 0, stream, text, nt, B, N, td, table, pos_table, drop_text, out, filler);
+    hipLaunchKernelGGL(text_gather_kernel, dim3(B * N), dim3(256), 0, stream, text, nt, B, N, td, table, pos_table, pos_rows, drop_text, out, filler);
     F5_LAUNCH_CHECK();
     return 0;
 }

@@ -43,6 +43,10 @@ int launch_pack_time_token(int precision, const float* h, const void* branch, co
 int launch_pad_mask(const uint8_t* mask, int B, int N, uint8_t* dst, hipStream_t stream);                      // [B, N] -> [B, N + 1], leading 1
 int launch_drop_time_token(const float* src, int B, int N, int cols, float* dst, hipStream_t stream);          // [B * (N + 1), cols] -> [B * N, cols]
 int launch_add_f32(float* x, const float* y, size_t n, hipStream_t stream);                                    // x += y, n % 4 == 0
+// ---- MMDiT (reference model/backbones/mmdit.py)
+// nb byte segments src + b * src_bstride -> dst + b * dst_bstride (everything a multiple of 16 bytes)
+int launch_copy_segments(const void* src, size_t src_bstride_bytes, void* dst, size_t dst_bstride_bytes, size_t seg_bytes, int nb, hipStream_t stream);
+int launch_joint_mask(const uint8_t* mask, int B, int N, int nt, uint8_t* dst, hipStream_t stream);  // [B, N] -> [B, N + nt], trailing 1s
 // depthwise Conv1d(k=7, pad=3) along the sequence (+bias) then LayerNorm(eps 1e-6, affine) -> activation dtype
 // x f32 [B*N, C]; wt f32 [7][C] (tap-major); out [B*N, C]
 int launch_dwconv7_ln(int precision_out, const float* x, int B, int N, int C, const float* wt, const float* cbias, const float* ln_w,
@@ -51,7 +55,7 @@ int launch_dwconv7_ln(int precision_out, const float* x, int B, int N, int C, co
 int launch_grn(int precision, void* h, int B, int N, int C, const float* gamma, const float* beta, float* scratch /*[B*C + B]*/,
                hipStream_t stream);
 // text ids -> embedding rows (+ abs-pos table) ; also writes filler flags [B*N] (1 where the id is the filler 0)
-int launch_text_gather(const int32_t* text, int nt, int B, int N, int td, const float* table, const float* pos_table /*or null*/,
+int launch_text_gather(const int32_t* text, int nt, int B, int N, int td, const float* table, const float* pos_table /*or null*/, int pos_rows,
                        int drop_text, float* out, uint8_t* filler, hipStream_t stream);
 int launch_mask_rows(float* x, int rows, int cols, const uint8_t* zero_flags, hipStream_t stream);
 // sinusoidal timestep embedding (modules.py:149-161): t [n] -> out [n, 256]

@@ -28,6 +28,9 @@ struct BlockW {
     // UNetT layers (unett.py:139-171): skip projection [D, 2D] of the later half (concat type), RMSNorm gains
     void* w_skip = nullptr;
     float *g_attn = nullptr, *g_ff = nullptr;
+    // MMDiT blocks (modules.py:646-707): the text stream's own projections; absent (null) in the last, context_pre_only block except w_qkv_c
+    void *w_qkv_c = nullptr, *w_o_c = nullptr, *w_ff1_c = nullptr, *w_ff2_c = nullptr;
+    float *b_qkv_c = nullptr, *b_o_c = nullptr, *b_ff1_c = nullptr, *b_ff2_c = nullptr;
 };
 struct TextBlockW {
     float *dw_wt = nullptr, *dw_b = nullptr, *ln_w = nullptr, *ln_b = nullptr, *b1 = nullptr, *gamma = nullptr, *beta = nullptr, *b2 = nullptr;
@@ -53,6 +56,8 @@ struct f5_model_s {
     float* b_out = nullptr;
     float* g_out = nullptr;  // UNetT: norm_out.g
     int td_pad = 0;          // text_dim rounded up to the GEMM's K granule (E2-TTS: text_dim = mel_dim = 100)
+    int in_td = 0;           // text columns of the input projection (text_dim; 0 for MMDiT, whose text is a stream of its own)
+    int text_pos_rows = 4096;  // rows of the sinusoidal table added to the text embedding (dit.py:41; 1024 mmdit.py:37)
     float inv_freq[32];
 };
 
@@ -111,6 +116,13 @@ struct f5_plan_s {
     void* catT = nullptr;              // cat(x, skip) of the concat skip connection [rows, 2D], activation dtype
     uint8_t* mask1 = nullptr;          // key mask with the leading 1 of the time token
     std::vector<float*> skips;         // depth / 2 saved streams
+    // MMDiT (mmdit.py:146-190): the text is a second residual stream of nt tokens per utterance; attention runs over [frames | text]
+    float* cres = nullptr;             // text stream [2B * nt, D] f32
+    void* qkvJ = nullptr;              // q|k|v of the joint sequence [2B * (N + nt), 3 * inner]
+    void* attJ = nullptr;              // attention output over the joint sequence [2B * (N + nt), inner]
+    uint8_t* maskJ = nullptr;          // key mask with trailing 1s over the text
+    const float* c_src[2] = {nullptr, nullptr};  // text embeddings the stream starts from at every evaluation (cond rows, then uncond rows)
+    int c_nt = 0, c_rows_each = 0;
     int fallbacks = 0;             // calls repeated with fp32 storage so far (f5_plan_get_option "residual_fallbacks")
     unsigned sat_amax_bits = 0;    // what the last event saw: largest finite |element| (float bits) and whether a NaN was read
     bool sat_nan = false;
@@ -157,7 +169,9 @@ extern "C" int f5_model_create(const f5_dit_config* c, f5_model_t* out) {
     if (c->dim <= 0 || c->dim % 128 != 0 || c->dim > 2048) return f5_fail(F5_EINVAL, "dim=%d must be a multiple of 128 (<= 2048)", c->dim);
     if (c->depth <= 0 || c->heads <= 0 || c->ff_inner <= 0 || c->ff_inner % 32 != 0) return f5_fail(F5_EINVAL, "bad depth/heads/ff_inner");
     if (c->mel_dim <= 0 || c->mel_dim > MELP || c->mel_dim % 4 != 0) return f5_fail(F5_EINVAL, "mel_dim=%d unsupported", c->mel_dim);
-    if (c->backbone != F5_BACKBONE_DIT && c->backbone != F5_BACKBONE_UNETT) return f5_fail(F5_EINVAL, "bad backbone");
+    if (c->backbone != F5_BACKBONE_DIT && c->backbone != F5_BACKBONE_UNETT && c->backbone != F5_BACKBONE_MMDIT) return f5_fail(F5_EINVAL, "bad backbone");
+    if (c->backbone == F5_BACKBONE_MMDIT && (c->text_dim != c->dim || c->conv_layers != 0))
+        return f5_fail(F5_EINVAL, "MMDiT: text_dim must equal dim and conv_layers be 0 (mmdit.py:101: TextEmbedding(dim, ...))");
     if (c->backbone == F5_BACKBONE_UNETT && (c->depth % 2 != 0 || c->skip_connect < F5_SKIP_CONCAT || c->skip_connect > F5_SKIP_NONE))
         return f5_fail(F5_EINVAL, "UNetT: depth must be even (unett.py:120) and skip_connect one of F5_SKIP_*");
     if (c->text_dim <= 0 || c->text_dim % 4 != 0 || c->text_dim > 1024 || (c->conv_layers > 0 && c->text_dim % 32 != 0))
@@ -169,9 +183,13 @@ extern "C" int f5_model_create(const f5_dit_config* c, f5_model_t* out) {
     m->cfg = *c;
     const int64_t D = c->dim, td = c->text_dim, inner = (int64_t)c->heads * 64, ff = c->ff_inner, mel = c->mel_dim;
     m->inner = (int)inner;
-    m->modrow = c->backbone == F5_BACKBONE_UNETT ? 0 : (int)(c->depth * 6 * D + 2 * D);
-    m->td_pad = (int)round_up(c->text_dim, 32);
-    m->rope_heads = (c->pe_attn_head <= 0 || c->pe_attn_head > c->heads) ? c->heads : c->pe_attn_head;
+    const bool mm = c->backbone == F5_BACKBONE_MMDIT;
+    // AdaLN rows per evaluation time.  DiT: 6D per block + 2D.  MMDiT: [x 6D | c 6D] per block, [x 6D | c 2D] in the last, + 2D.
+    m->modrow = c->backbone == F5_BACKBONE_UNETT ? 0 : mm ? (int)(c->depth * 12 * D - 4 * D + 2 * D) : (int)(c->depth * 6 * D + 2 * D);
+    m->in_td = mm ? 0 : c->text_dim;
+    m->td_pad = (int)round_up(m->in_td, 32);
+    m->text_pos_rows = mm ? 1024 : 4096;
+    m->rope_heads = (mm || c->pe_attn_head <= 0 || c->pe_attn_head > c->heads) ? c->heads : c->pe_attn_head;  // (JointAttnProcessor: every head)
     SlotMap& s = m->slots;
     add_slot(s, "time_embed.time_mlp.0.weight", {D, 256});
     add_slot(s, "time_embed.time_mlp.0.bias", {D});
@@ -191,13 +209,42 @@ extern "C" int f5_model_create(const f5_dit_config* c, f5_model_t* out) {
         add_slot(s, p + "pwconv2.weight", {td, 2 * td});
         add_slot(s, p + "pwconv2.bias", {td});
     }
-    add_slot(s, "input_embed.proj.weight", {D, 2 * mel + td});
-    add_slot(s, "input_embed.proj.bias", {D});
+    const std::string in_pre = mm ? "audio_embed." : "input_embed.";  // mmdit.py:69-71: AudioEmbedding.linear(2 mel -> dim) + conv_pos_embed
+    add_slot(s, in_pre + (mm ? "linear.weight" : "proj.weight"), {D, 2 * mel + m->in_td});
+    add_slot(s, in_pre + (mm ? "linear.bias" : "proj.bias"), {D});
     for (int i = 0; i < 4; i += 2) {
-        add_slot(s, "input_embed.conv_pos_embed.conv1d." + std::to_string(i) + ".weight", {D, D / 16, 31});
-        add_slot(s, "input_embed.conv_pos_embed.conv1d." + std::to_string(i) + ".bias", {D});
+        add_slot(s, in_pre + "conv_pos_embed.conv1d." + std::to_string(i) + ".weight", {D, D / 16, 31});
+        add_slot(s, in_pre + "conv_pos_embed.conv1d." + std::to_string(i) + ".bias", {D});
     }
-    if (c->backbone == F5_BACKBONE_UNETT) {  // unett.py:139-175: layers.<i> = [skip_proj | None, attn_norm, attn, ff_norm, ff]
+    if (mm) {  // mmdit.py:110-124: MMDiTBlock(context_pre_only = last)
+        for (int i = 0; i < c->depth; ++i) {
+            const std::string p = "transformer_blocks." + std::to_string(i) + ".";
+            const bool last = i == c->depth - 1;
+            add_slot(s, p + "attn_norm_c.linear.weight", {(last ? 2 : 6) * D, D});
+            add_slot(s, p + "attn_norm_c.linear.bias", {(last ? 2 : 6) * D});
+            add_slot(s, p + "attn_norm_x.linear.weight", {6 * D, D});
+            add_slot(s, p + "attn_norm_x.linear.bias", {6 * D});
+            for (const char* nm : {"to_q", "to_k", "to_v", "to_q_c", "to_k_c", "to_v_c"}) {
+                add_slot(s, p + "attn." + nm + ".weight", {inner, D});
+                add_slot(s, p + "attn." + nm + ".bias", {inner});
+            }
+            add_slot(s, p + "attn.to_out.0.weight", {D, inner});
+            add_slot(s, p + "attn.to_out.0.bias", {D});
+            if (!last) {
+                add_slot(s, p + "attn.to_out_c.weight", {D, inner});
+                add_slot(s, p + "attn.to_out_c.bias", {D});
+            }
+            for (const char* sx : {"ff_x.", "ff_c."}) {
+                if (last && sx[3] == 'c') continue;
+                add_slot(s, p + sx + "ff.0.0.weight", {ff, D});
+                add_slot(s, p + sx + "ff.0.0.bias", {ff});
+                add_slot(s, p + sx + "ff.2.weight", {D, ff});
+                add_slot(s, p + sx + "ff.2.bias", {D});
+            }
+        }
+        add_slot(s, "norm_out.linear.weight", {2 * D, D});
+        add_slot(s, "norm_out.linear.bias", {2 * D});
+    } else if (c->backbone == F5_BACKBONE_UNETT) {  // unett.py:139-175: layers.<i> = [skip_proj | None, attn_norm, attn, ff_norm, ff]
         for (int i = 0; i < c->depth; ++i) {
             const std::string p = "layers." + std::to_string(i) + ".";
             if (i >= c->depth / 2 && c->skip_connect == F5_SKIP_CONCAT) add_slot(s, p + "0.weight", {D, 2 * D});
@@ -282,6 +329,25 @@ extern "C" int f5_model_finalize(f5_model_t m) {
     F5_TRY(f5_upload_f32(A, H(m, "time_embed.time_mlp.2.weight").data(), D * D, &m->w_t2));
     F5_TRY(f5_upload_f32(A, H(m, "time_embed.time_mlp.2.bias").data(), D, &m->b_t2));
     // AdaLN linears of every block + the final one, concatenated (fp32)
+    const bool mm = c.backbone == F5_BACKBONE_MMDIT;
+    if (mm) {
+        std::vector<float> w((size_t)m->modrow * D), b(m->modrow);
+        size_t row = 0;
+        auto put = [&](const std::string& pre, size_t n) {
+            memcpy(&w[row * D], H(m, pre + "weight").data(), n * D * sizeof(float));
+            memcpy(&b[row], H(m, pre + "bias").data(), n * sizeof(float));
+            row += n;
+        };
+        for (int i = 0; i < c.depth; ++i) {
+            const std::string p = "transformer_blocks." + std::to_string(i) + ".";
+            put(p + "attn_norm_x.linear.", 6 * D);
+            put(p + "attn_norm_c.linear.", (i == c.depth - 1 ? 2 : 6) * D);
+        }
+        put("norm_out.linear.", 2 * D);
+        if (row != (size_t)m->modrow) return f5_fail(F5_ESTATE, "MMDiT AdaLN layout");
+        F5_TRY(f5_upload_f32(A, w.data(), w.size(), &m->w_adaln));
+        F5_TRY(f5_upload_f32(A, b.data(), b.size(), &m->b_adaln));
+    }
     if (c.backbone == F5_BACKBONE_DIT) {
         std::vector<float> w((size_t)m->modrow * D), b(m->modrow);
         for (int i = 0; i < c.depth; ++i) {
@@ -296,13 +362,14 @@ extern "C" int f5_model_finalize(f5_model_t m) {
     }
     // text embedder
     F5_TRY(f5_upload_f32(A, H(m, "text_embed.text_embed.weight").data(), (size_t)(c.text_num_embeds + 1) * td, &m->text_table));
-    if (c.conv_layers > 0) {
-        // precompute_freqs_cis(text_dim, 4096): [cos | sin], theta_j = 10000^(-2j/dim)  (modules.py:196-207)
-        std::vector<float> pos((size_t)4096 * td);
+    if (c.conv_layers > 0 || mm) {
+        // precompute_freqs_cis(text_dim, 4096 | 1024): [cos | sin], theta_j = 10000^(-2j/dim)  (modules.py:196-207)
+        const int npos = m->text_pos_rows;
+        std::vector<float> pos((size_t)npos * td);
         const int half = (int)td / 2;
         for (int j = 0; j < half; ++j) {
             const float inv = 1.0f / powf(10000.0f, (float)(2 * j) / (float)td);
-            for (int p = 0; p < 4096; ++p) {
+            for (int p = 0; p < npos; ++p) {
                 const float ang = (float)p * inv;
                 pos[(size_t)p * td + j] = cosf(ang);
                 pos[(size_t)p * td + half + j] = sinf(ang);
@@ -331,17 +398,17 @@ extern "C" int f5_model_finalize(f5_model_t m) {
     }
     // input projection split: columns [x | cond | text]  (dit.py:88,95 concat order)
     {
-        const std::vector<float>& w = H(m, "input_embed.proj.weight");
-        const size_t kin = 2 * mel + td, kct = MELP + (size_t)m->td_pad;  // (text columns zero-padded to the GEMM's K granule)
+        const std::vector<float>& w = H(m, mm ? "audio_embed.linear.weight" : "input_embed.proj.weight");
+        const size_t itd = m->in_td, kin = 2 * mel + itd, kct = MELP + (size_t)m->td_pad;  // (text columns zero-padded to the GEMM's K granule)
         std::vector<float> wx(D * MELP, 0.f), wct(D * kct, 0.f);
         for (size_t n = 0; n < D; ++n) {
             for (size_t k = 0; k < mel; ++k) wx[n * MELP + k] = w[n * kin + k];
             for (size_t k = 0; k < mel; ++k) wct[n * kct + k] = w[n * kin + mel + k];
-            for (size_t k = 0; k < td; ++k) wct[n * kct + MELP + k] = w[n * kin + 2 * mel + k];
+            for (size_t k = 0; k < itd; ++k) wct[n * kct + MELP + k] = w[n * kin + 2 * mel + k];
         }
         F5_TRY(f5_upload_t(A, P, wx.data(), wx.size(), &m->w_x));
         F5_TRY(f5_upload_t(A, P, wct.data(), wct.size(), &m->w_ct));
-        F5_TRY(f5_upload_f32(A, H(m, "input_embed.proj.bias").data(), D, &m->b_in));
+        F5_TRY(f5_upload_f32(A, H(m, mm ? "audio_embed.linear.bias" : "input_embed.proj.bias").data(), D, &m->b_in));
     }
     // grouped conv (k=31, groups=16) -> tap-major [31][D][win], zero outside each output row's own group
     {
@@ -355,7 +422,7 @@ extern "C" int f5_model_finalize(f5_model_t m) {
         m->conv_cg = cg;
         m->conv_win = win;
         for (int li = 0; li < 2; ++li) {
-            const std::string p = "input_embed.conv_pos_embed.conv1d." + std::to_string(li * 2) + ".";
+            const std::string p = std::string(mm ? "audio_embed." : "input_embed.") + "conv_pos_embed.conv1d." + std::to_string(li * 2) + ".";
             const std::vector<float>& w = H(m, p + "weight");  // [D, cg, 31]
             std::vector<float> r((size_t)31 * D * win, 0.f);
             for (int n = 0; n < (int)D; ++n) {
@@ -374,34 +441,49 @@ extern "C" int f5_model_finalize(f5_model_t m) {
     const bool un = c.backbone == F5_BACKBONE_UNETT;
     for (int i = 0; i < c.depth; ++i) {
         const std::string p = (un ? "layers." : "transformer_blocks.") + std::to_string(i) + ".";
-        const std::string pa = p + (un ? "2." : "attn."), pf = p + (un ? "4." : "ff.");
+        const std::string pa = p + (un ? "2." : "attn."), pf = p + (un ? "4." : mm ? "ff_x." : "ff.");
         BlockW& b = m->blocks[i];
-        std::vector<float> w(3 * inner * D), bias(3 * inner);
-        const char* nm[3] = {"to_q", "to_k", "to_v"};
-        for (int j = 0; j < 3; ++j) {
-            memcpy(&w[(size_t)j * inner * D], H(m, pa + nm[j] + ".weight").data(), inner * D * sizeof(float));
-            memcpy(&bias[(size_t)j * inner], H(m, pa + nm[j] + ".bias").data(), inner * sizeof(float));
-        }
-        if (c.rope_layout == F5_ROPE_HALF_SPLIT) {
-            // The kernels rotate ADJACENT feature pairs.  The half-split form turns (j, j + 32) with frequency j; QK^T is invariant under
-            // one permutation of the 64 features of a head applied to q and k alike, so the q/k output rows are re-ordered once here
-            // (new 2j <- old j, new 2j+1 <- old j + 32) and the adjacent-pair rotation then IS the half-split rotation.  v is untouched.
-            std::vector<float> row(D);
-            for (int part = 0; part < 2; ++part)
-                for (int hd = 0; hd < m->rope_heads; ++hd) {
-                    float* wb = &w[((size_t)part * inner + (size_t)hd * 64) * D];
-                    float* bb = &bias[(size_t)part * inner + (size_t)hd * 64];
-                    std::vector<float> wo(wb, wb + 64 * D), bo(bb, bb + 64);
-                    for (int j = 0; j < 32; ++j) {
-                        memcpy(wb + (size_t)(2 * j) * D, &wo[(size_t)j * D], D * sizeof(float));
-                        memcpy(wb + (size_t)(2 * j + 1) * D, &wo[(size_t)(j + 32) * D], D * sizeof(float));
-                        bb[2 * j] = bo[j];
-                        bb[2 * j + 1] = bo[j + 32];
+        // fused [3 * inner, D] projection of one stream (sfx "" = frames, "_c" = MMDiT's text stream)
+        auto fuse_qkv = [&](const std::string& sfx, void** wdst, float** bdst) -> int {
+            std::vector<float> w(3 * inner * D), bias(3 * inner);
+            const char* nm[3] = {"to_q", "to_k", "to_v"};
+            for (int j = 0; j < 3; ++j) {
+                memcpy(&w[(size_t)j * inner * D], H(m, pa + nm[j] + sfx + ".weight").data(), inner * D * sizeof(float));
+                memcpy(&bias[(size_t)j * inner], H(m, pa + nm[j] + sfx + ".bias").data(), inner * sizeof(float));
+            }
+            if (c.rope_layout == F5_ROPE_HALF_SPLIT) {
+                // The kernels rotate ADJACENT feature pairs.  The half-split form turns (j, j + 32) with frequency j; QK^T is invariant under
+                // one permutation of the 64 features of a head applied to q and k alike, so the q/k output rows are re-ordered once here
+                // (new 2j <- old j, new 2j+1 <- old j + 32) and the adjacent-pair rotation then IS the half-split rotation.  v is untouched.
+                // (MMDiT: the same permutation on both streams' q and k, which meet in one QK^T.)
+                for (int part = 0; part < 2; ++part)
+                    for (int hd = 0; hd < m->rope_heads; ++hd) {
+                        float* wb = &w[((size_t)part * inner + (size_t)hd * 64) * D];
+                        float* bb = &bias[(size_t)part * inner + (size_t)hd * 64];
+                        std::vector<float> wo(wb, wb + 64 * D), bo(bb, bb + 64);
+                        for (int j = 0; j < 32; ++j) {
+                            memcpy(wb + (size_t)(2 * j) * D, &wo[(size_t)j * D], D * sizeof(float));
+                            memcpy(wb + (size_t)(2 * j + 1) * D, &wo[(size_t)(j + 32) * D], D * sizeof(float));
+                            bb[2 * j] = bo[j];
+                            bb[2 * j + 1] = bo[j + 32];
+                        }
                     }
-                }
+            }
+            F5_TRY(f5_upload_t(A, P, w.data(), w.size(), wdst));
+            return f5_upload_f32(A, bias.data(), bias.size(), bdst);
+        };
+        F5_TRY(fuse_qkv("", &b.w_qkv, &b.b_qkv));
+        if (mm) {
+            F5_TRY(fuse_qkv("_c", &b.w_qkv_c, &b.b_qkv_c));
+            if (i != c.depth - 1) {
+                F5_TRY(f5_upload_t(A, P, H(m, pa + "to_out_c.weight").data(), D * inner, &b.w_o_c));
+                F5_TRY(f5_upload_f32(A, H(m, pa + "to_out_c.bias").data(), D, &b.b_o_c));
+                F5_TRY(f5_upload_t(A, P, H(m, p + "ff_c.ff.0.0.weight").data(), ff * D, &b.w_ff1_c));
+                F5_TRY(f5_upload_f32(A, H(m, p + "ff_c.ff.0.0.bias").data(), ff, &b.b_ff1_c));
+                F5_TRY(f5_upload_t(A, P, H(m, p + "ff_c.ff.2.weight").data(), D * ff, &b.w_ff2_c));
+                F5_TRY(f5_upload_f32(A, H(m, p + "ff_c.ff.2.bias").data(), D, &b.b_ff2_c));
+            }
         }
-        F5_TRY(f5_upload_t(A, P, w.data(), w.size(), &b.w_qkv));
-        F5_TRY(f5_upload_f32(A, bias.data(), bias.size(), &b.b_qkv));
         F5_TRY(f5_upload_t(A, P, H(m, pa + "to_out.0.weight").data(), D * inner, &b.w_o));
         F5_TRY(f5_upload_f32(A, H(m, pa + "to_out.0.bias").data(), D, &b.b_o));
         F5_TRY(f5_upload_t(A, P, H(m, pf + "ff.0.0.weight").data(), ff * D, &b.w_ff1));
@@ -509,6 +591,13 @@ extern "C" int f5_plan_create(f5_model_t m, int max_batch, int max_seq, int max_
             }
         if ((rc = f5_upload_f32(A, rope.data(), rope.size(), &p->rope))) break;
         p->rope_n = rope_n;
+        if (c.backbone == F5_BACKBONE_MMDIT) {
+            const size_t rowsJ = (size_t)round_up(2 * bn * 2, 256);  // text length <= max_seq (f5_sample / f5_mmdit_forward check it)
+            if ((rc = A.alloc_t(&p->cres, rows * D))) break;
+            if ((rc = A.alloc(&p->qkvJ, rowsJ * 3 * inner * es))) break;
+            if ((rc = A.alloc(&p->attJ, rowsJ * inner * es))) break;
+            if ((rc = A.alloc_t(&p->maskJ, rowsJ))) break;
+        }
         if (un) {
             if ((rc = A.alloc_t(&p->xin_res, rows * D))) break;
             if ((rc = A.alloc_t(&p->vout_s, rows * MELP))) break;
@@ -677,7 +766,7 @@ int g_sync_evals = 0;  // diagnostic knob ("sync_evals"): an eager sample() sync
 // fp16 residual storage for this plan's evaluations (bf16 mode without stage taps; the plan option overrides the process-wide knob)
 static bool plan_res_f16(const f5_plan_s* p) {
     const bool want = p->res_f16 < 0 ? g_res_f16 != 0 : p->res_f16 != 0;
-    if (p->m->cfg.backbone != F5_BACKBONE_DIT) return false;  // (UNetT keeps its stream in fp32)
+    if (p->m->cfg.backbone != F5_BACKBONE_DIT) return false;  // (UNetT and MMDiT keep their streams in fp32)
     return want && p->taps.empty() && g_ln_defer && p->m->cfg.precision == F5_PREC_BF16 && p->xres16 && p->base16;
 }
 
@@ -725,9 +814,15 @@ static int compute_modulation(f5_plan_s* p, const float* tvals_dev, int n, hipSt
 static int compute_text_embed(f5_plan_s* p, const int32_t* text, int nt, int B, int N, int drop_text, float* out, hipStream_t st) {
     f5_model_s* m = p->m;
     const f5_dit_config& c = m->cfg;
-    const int td = c.text_dim, P = c.precision, rows = B * N;
+    const int td = c.text_dim, P = c.precision;
+    if (c.backbone == F5_BACKBONE_MMDIT) {  // mmdit.py:40-61: [B, nt, dim], not padded to the frame count; table of 1024 positions
+        F5_TRY(launch_text_gather(text, nt, B, nt, td, m->text_table, m->text_pos, m->text_pos_rows, drop_text, out, p->filler, st));
+        if (c.text_mask_padding) F5_TRY(launch_mask_rows(out, B * nt, td, p->filler, st));
+        return 0;
+    }
+    const int rows = B * N;
     const bool extra = c.conv_layers > 0;
-    F5_TRY(launch_text_gather(text, nt, B, N, td, m->text_table, extra ? m->text_pos : nullptr, drop_text, out, p->filler, st));
+    F5_TRY(launch_text_gather(text, nt, B, N, td, m->text_table, extra ? m->text_pos : nullptr, m->text_pos_rows, drop_text, out, p->filler, st));
     if (!extra) return 0;
     const bool mp = c.text_mask_padding != 0;
     if (mp) F5_TRY(launch_mask_rows(out, rows, td, p->filler, st));
@@ -753,7 +848,7 @@ static int compute_base(f5_plan_s* p, const float* cond, const int32_t* lens, co
                         hipStream_t st) {
     f5_model_s* m = p->m;
     const f5_dit_config& c = m->cfg;
-    const int D = c.dim, td = c.text_dim, P = c.precision, kct = MELP + m->td_pad;  // (columns td .. td_pad stay zero: the arena zero-fills)
+    const int D = c.dim, td = m->in_td, P = c.precision, kct = MELP + m->td_pad;  // (columns td .. td_pad stay zero: the arena zero-fills)
     const size_t es = f5_elem_size(P);
     void* ab = (char*)p->abase + row0 * kct * es;
     F5_TRY(launch_pack_base(P, cond, lens, te, nb, N, c.mel_dim, MELP, td, zero_cond, ab, kct, st));
@@ -1007,11 +1102,119 @@ static int unett_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, co
     return launch_drop_time_token(p->vout_s, nb, N, MELP, p->vout, st);
 }
 
+// one evaluation of the MMDiT backbone (reference model/backbones/mmdit.py:146-190, MMDiTBlock modules.py:646-707, JointAttnProcessor :509-606) over
+// `nb` batch rows.  Two fp32 residual streams: frames `xres` [nb * N, D] and text `cres` [nb * nt, D] (restarted from p->c_src at every
+// evaluation: unlike DiT's text embedding the text stream passes through the time-conditioned blocks).  Each block projects both streams with
+// their own weights (RoPE per stream, positions from 0), gathers q|k|v into the joint [frames | text] sequence of every utterance, runs one
+// attention over it, scatters the result back and applies the gated out-projection / FF updates to each stream in place (EPI_RESID).
+static int mmdit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, const float* modp, int mod_bstride, const uint8_t* mask, hipStream_t st) {
+    f5_model_s* m = p->m;
+    const f5_dit_config& c = m->cfg;
+    const int D = c.dim, P = c.precision, inner = m->inner, ff = c.ff_inner, nt = p->c_nt, S = N + nt, rows = nb * N, rows_c = nb * nt;
+    const size_t es = f5_elem_size(P);
+    if (nt <= 0 || !p->c_src[0]) return f5_fail(F5_ESTATE, "MMDiT: no text stream staged");
+    // c = text_embed(text)  (:163-173)
+    for (int h = 0; h < 2; ++h) {
+        const int r0 = h * p->c_rows_each, nr = std::min(rows_c - r0, p->c_rows_each);
+        if (nr <= 0) break;
+        if (!p->c_src[h]) return f5_fail(F5_ESTATE, "MMDiT: text stream of the second branch missing");
+        F5_HIP(hipMemcpyAsync(p->cres + (size_t)r0 * D, p->c_src[h], (size_t)nr * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    // AudioEmbedding (:69-79): h = Linear(cat(x, cond)); x = conv_pos_embed(h) + h   (the cond half of the linear is hoisted into `base`)
+    F5_TRY(launch_convert_pad(P, x, c.mel_dim, xrows, c.mel_dim, MELP, p->xin, MELP, st));
+    GemmParams g = gp_zero();
+    g.A = p->xin; g.lda = MELP; g.W = m->w_x; g.ldw = MELP; g.M = rows; g.N = D; g.K = MELP;
+    g.a_row_mod = xrows < rows ? xrows : 0;
+    g.addend = p->base; g.ldadd = D; g.out_t = p->hT; g.ldo = D; g.out_f = p->xres; g.ldof = D;
+    F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_ADD2, st));
+    for (int li = 0; li < 2; ++li) {
+        g = gp_zero();
+        g.A = li == 0 ? p->hT : p->cT; g.lda = D; g.W = m->w_conv[li]; g.M = rows; g.N = D; g.K = 31 * m->conv_win;
+        g.bias = m->b_conv[li]; g.act = ACT_MISH; g.rows_per_batch = N; g.conv_cg = m->conv_cg; g.conv_win = m->conv_win;
+        g.out_t = li == 0 ? p->cT : p->yT; g.ldo = D;
+        F5_TRY(run_gemm(p, g, GEMM_CONV31, li == 0 ? EPI_STORE_T : EPI_GATE_T, st));
+    }
+    const uint8_t* maskJ = nullptr;
+    if (mask) {  // modules.py:573: no mask over the text keys
+        F5_TRY(launch_joint_mask(mask, nb, N, nt, p->maskJ, st));
+        maskJ = p->maskJ;
+    }
+    const size_t qrow = (size_t)3 * inner * es, arow = (size_t)inner * es;
+    // one stream's linear that updates it in place: stream += gate * (A . W^T + b), padded query rows of the frames untouched (:596-599)
+    auto resid = [&](const void* A, int lda, const void* W, const float* bias, int K, float* stream, int M, int rpb, const float* gate, const uint8_t* rm) {
+        GemmParams q = gp_zero();
+        q.A = A; q.lda = lda; q.W = W; q.ldw = K; q.M = M; q.N = D; q.K = K;
+        q.bias = bias; q.out_f = stream; q.ldof = D; q.gate = gate; q.gate_bstride = mod_bstride; q.rows_per_batch = rpb; q.rowmask = rm;
+        return run_gemm(p, q, GEMM_DENSE, EPI_RESID, st);
+    };
+    for (int l = 0; l < c.depth; ++l) {
+        const BlockW& b = m->blocks[l];
+        const bool last = l == c.depth - 1;
+        const float* mx = modp + (size_t)l * 12 * D;  // attn_norm_x: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp (modules.py:312)
+        const float* mc = mx + (size_t)6 * D;         // attn_norm_c: the same six, or (scale, shift) of AdaLayerNorm_Final in the last block (:333)
+        // frames: norm_x -> q|k|v with RoPE over positions 0 .. N-1
+        if (l == 0)  // (x += position-conv branch, written back)
+            F5_TRY(launch_layernorm_add(P, p->xres, D, rows, D, p->yT, D, mx + D, mx, mod_bstride, N, 1, p->hT, D, st));
+        else
+            F5_TRY(launch_layernorm(P, p->xres, D, rows, D, mx + D, mx, mod_bstride, N, 1, p->hT, D, st));
+        g = gp_zero();
+        g.A = p->hT; g.lda = D; g.W = b.w_qkv; g.ldw = D; g.M = rows; g.N = 3 * inner; g.K = D;
+        g.bias = b.b_qkv; g.out_t = p->qkv; g.ldo = 3 * inner; g.rows_per_batch = N;
+        g.rope = p->rope; g.rope_inner = inner; g.rope_heads = m->rope_heads;
+        F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_ROPE_T, st));
+        F5_TRY(launch_copy_segments(p->qkv, (size_t)N * qrow, p->qkvJ, (size_t)S * qrow, (size_t)N * qrow, nb, st));
+        // text: norm_c -> q|k|v with RoPE over positions 0 .. nt-1
+        if (last)
+            F5_TRY(launch_layernorm(P, p->cres, D, rows_c, D, mc, mc + D, mod_bstride, nt, 1, p->hT, D, st));
+        else
+            F5_TRY(launch_layernorm(P, p->cres, D, rows_c, D, mc + D, mc, mod_bstride, nt, 1, p->hT, D, st));
+        g = gp_zero();
+        g.A = p->hT; g.lda = D; g.W = b.w_qkv_c; g.ldw = D; g.M = rows_c; g.N = 3 * inner; g.K = D;
+        g.bias = b.b_qkv_c; g.out_t = p->qkv; g.ldo = 3 * inner; g.rows_per_batch = nt;
+        g.rope = p->rope; g.rope_inner = inner; g.rope_heads = m->rope_heads;
+        F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_ROPE_T, st));
+        F5_TRY(launch_copy_segments(p->qkv, (size_t)nt * qrow, (char*)p->qkvJ + (size_t)N * qrow, (size_t)S * qrow, (size_t)nt * qrow, nb, st));
+        {
+            int kind = 0;
+            if (p->attn_kernel != 0 && attention_fast_supported(P, S, c.heads)) kind = 1;
+            F5_TRY(launch_attention(P, kind, nb, S, c.heads, p->qkvJ, 3 * inner, maskJ, p->attJ, inner, st));
+        }
+        // text: c += gate_msa * to_out_c(attn_c); c += gate_mlp * ff_c(norm)   (:697-706; nothing in the context_pre_only block)
+        if (!last) {
+            F5_TRY(launch_copy_segments((const char*)p->attJ + (size_t)N * arow, (size_t)S * arow, p->cT, (size_t)nt * arow, (size_t)nt * arow, nb, st));
+            F5_TRY(resid(p->cT, inner, b.w_o_c, b.b_o_c, inner, p->cres, rows_c, nt, mc + 2 * D, nullptr));
+            F5_TRY(launch_layernorm(P, p->cres, D, rows_c, D, mc + 4 * D, mc + 3 * D, mod_bstride, nt, 1, p->hT, D, st));
+            g = gp_zero();
+            g.A = p->hT; g.lda = D; g.W = b.w_ff1_c; g.ldw = D; g.M = rows_c; g.N = ff; g.K = D;
+            g.bias = b.b_ff1_c; g.act = ACT_GELU_TANH; g.out_t = p->ffh; g.ldo = ff;
+            F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_STORE_T, st));
+            F5_TRY(resid(p->ffh, ff, b.w_ff2_c, b.b_ff2_c, ff, p->cres, rows_c, nt, mc + 5 * D, nullptr));
+        }
+        // frames: x += gate_msa * to_out(attn_x) (0 on padded rows); x += gate_mlp * ff_x(norm)   (:709-713)
+        F5_TRY(launch_copy_segments(p->attJ, (size_t)S * arow, p->cT, (size_t)N * arow, (size_t)N * arow, nb, st));
+        F5_TRY(resid(p->cT, inner, b.w_o, b.b_o, inner, p->xres, rows, N, mx + 2 * D, mask));
+        F5_TRY(launch_layernorm(P, p->xres, D, rows, D, mx + 4 * D, mx + 3 * D, mod_bstride, N, 1, p->hT, D, st));
+        g = gp_zero();
+        g.A = p->hT; g.lda = D; g.W = b.w_ff1; g.ldw = D; g.M = rows; g.N = ff; g.K = D;
+        g.bias = b.b_ff1; g.act = ACT_GELU_TANH; g.out_t = p->ffh; g.ldo = ff;
+        F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_STORE_T, st));
+        F5_TRY(resid(p->ffh, ff, b.w_ff2, b.b_ff2, ff, p->xres, rows, N, mx + 5 * D, nullptr));
+    }
+    const float* mf = modp + (size_t)m->modrow - 2 * D;  // norm_out: (scale, shift) (modules.py:333)
+    F5_TRY(launch_layernorm(P, p->xres, D, rows, D, mf, mf + D, mod_bstride, N, 1, p->hT, D, st));
+    g = gp_zero();
+    g.A = p->hT; g.lda = D; g.W = m->w_out; g.ldw = D; g.M = rows; g.N = MELP; g.K = D;
+    g.bias = m->b_out; g.out_f = p->vout; g.ldof = MELP;
+    return run_gemm(p, g, GEMM_DENSE, EPI_STORE_F32, st);
+}
+
 // one network evaluation of whichever backbone the model is (plug point A)
 static int net_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, int time_row, int per_batch_rows, const uint8_t* mask, hipStream_t st) {
     f5_model_s* m = p->m;
     if (m->cfg.backbone == F5_BACKBONE_UNETT)
         return unett_eval(p, x, xrows, nb, N, p->temb + (size_t)time_row * m->cfg.dim, per_batch_rows ? m->cfg.dim : 0, mask, st);
+    if (m->cfg.backbone == F5_BACKBONE_MMDIT)
+        return mmdit_eval(p, x, xrows, nb, N, p->mod + (size_t)time_row * m->modrow, per_batch_rows ? m->modrow : 0, mask, st);
     return dit_eval(p, x, xrows, nb, N, p->mod + (size_t)time_row * m->modrow, per_batch_rows ? m->modrow : 0, mask, st);
 }
 
@@ -1033,11 +1236,31 @@ extern "C" int f5_dit_forward(f5_plan_t p, int B, int N, const float* x, const f
                               int drop_audio_cond, const uint8_t* mask, float* out, f5_stream_t stream) {
     F5_TRY(check_plan_shape(p, B, N));
     if (!x || !cond || !text_embed || !time || !out) return f5_fail(F5_EINVAL, "null argument");
+    if (p->m->cfg.backbone == F5_BACKBONE_MMDIT) return f5_fail(F5_ENOTSUP, "MMDiT: the text stream has its own length, call f5_mmdit_forward");
     hipStream_t st = (hipStream_t)stream;
     f5_model_s* m = p->m;
     p->mod_tv.clear();  // p->mod is overwritten with per-sample times
     F5_TRY(compute_modulation(p, time, B, st));
     F5_TRY(compute_base(p, cond, nullptr, text_embed, B, N, drop_audio_cond, 0, st));
+    F5_TRY(net_eval(p, x, B * N, B, N, 0, 1, mask, st));
+    return launch_convert_back(F5_PREC_FP32, p->vout, MELP, B * N, m->cfg.mel_dim, out, m->cfg.mel_dim, st);
+}
+
+extern "C" int f5_mmdit_forward(f5_plan_t p, int B, int N, int nt, const float* x, const float* cond, const float* text_embed, const float* time,
+                                int drop_audio_cond, const uint8_t* mask, float* out, f5_stream_t stream) {
+    F5_TRY(check_plan_shape(p, B, N));
+    if (!x || !cond || !text_embed || !time || !out) return f5_fail(F5_EINVAL, "null argument");
+    if (p->m->cfg.backbone != F5_BACKBONE_MMDIT) return f5_fail(F5_ENOTSUP, "f5_mmdit_forward needs an F5_BACKBONE_MMDIT model");
+    if (nt <= 0 || nt > p->maxN) return f5_fail(F5_EINVAL, "text length %d outside 1 .. the plan's max_seq %d", nt, p->maxN);
+    hipStream_t st = (hipStream_t)stream;
+    f5_model_s* m = p->m;
+    p->mod_tv.clear();  // p->mod is overwritten with per-sample times
+    F5_TRY(compute_modulation(p, time, B, st));
+    F5_TRY(compute_base(p, cond, nullptr, nullptr, B, N, drop_audio_cond, 0, st));
+    p->c_src[0] = text_embed;
+    p->c_src[1] = nullptr;
+    p->c_nt = nt;
+    p->c_rows_each = B * nt;
     F5_TRY(net_eval(p, x, B * N, B, N, 0, 1, mask, st));
     return launch_convert_back(F5_PREC_FP32, p->vout, MELP, B * N, m->cfg.mel_dim, out, m->cfg.mel_dim, st);
 }
@@ -1073,6 +1296,12 @@ static int sample_body(f5_plan_s* p, const SampleArgs& a, hipStream_t st) {
         p->rowbits_src = mask;
     }
     const int nb = a.cfg_on ? 2 * B : B;
+    if (c.backbone == F5_BACKBONE_MMDIT) {  // the text stream restarts from these rows at every evaluation (mmdit.py:163-173: the cached embeddings)
+        p->c_src[0] = p->te[0];
+        p->c_src[1] = a.cfg_on ? p->te[1] : nullptr;
+        p->c_nt = a.nt;
+        p->c_rows_each = B * a.nt;
+    }
     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
     if (g_sync_evals) (void)hipStreamIsCapturing(st, &capturing);
     for (int s = 0; s < a.steps; ++s) {
@@ -1190,7 +1419,9 @@ extern "C" int f5_sample(f5_plan_t p, int B, int N, const float* cond, const int
     f5_model_s* m = p->m;
     const int mel = m->cfg.mel_dim, bn = B * N;
     const size_t state = (size_t)bn * mel;
-    const int nt_eff = nt < N ? nt : N;  // tokens beyond the frame count are curtailed (dit.py:51)
+    const bool mmdit = m->cfg.backbone == F5_BACKBONE_MMDIT;
+    if (mmdit && nt > p->maxN) return f5_fail(F5_EINVAL, "MMDiT: text length %d exceeds the plan's max_seq %d", nt, p->maxN);
+    const int nt_eff = (mmdit || nt < N) ? nt : N;  // tokens beyond the frame count are curtailed (dit.py:51; MMDiT keeps them all, mmdit.py:40)
 
     // evaluation times / step coefficients, fp32 op order of torchdiffeq's fixed-grid solvers
     std::vector<float> tv(nev), cf(nev);

@@ -228,7 +228,7 @@ class DiT(nn.Module):
     def forward(self, x, cond, text, time, drop_audio_cond, drop_text, mask=None, cache=False):
         lib = _lib.load()
         batch, seq_len = x.shape[0], x.shape[1]
-        plan = self.plan(batch, seq_len, 1)
+        plan = self.plan(batch, self._plan_seq(seq_len, text.shape[1]), 1)
         if time.ndim == 0:
             time = time.repeat(batch)
         if cache:
@@ -247,9 +247,15 @@ class DiT(nn.Module):
         tf = time.to(device="cuda", dtype=torch.float32).contiguous()
         mk = None if mask is None else mask.to(device="cuda", dtype=torch.uint8).contiguous()
         out = torch.empty(batch, seq_len, self.mel_dim, device="cuda", dtype=torch.float32)
-        _lib.check(lib.f5_dit_forward(plan, batch, seq_len, _lib.ptr(xf), _lib.ptr(cf), _lib.ptr(text_embed), _lib.ptr(tf),
-                                      int(bool(drop_audio_cond)), _lib.ptr(mk), _lib.ptr(out), _lib.stream_ptr()), "dit_forward")
+        self._native_forward(lib, plan, batch, seq_len, xf, cf, text_embed, tf, int(bool(drop_audio_cond)), mk, out)
         return out.to(x.dtype) if x.dtype != torch.float32 else out
+
+    def _plan_seq(self, seq_len, text_len):
+        return seq_len  # (text beyond the frame count is curtailed, dit.py:51)
+
+    def _native_forward(self, lib, plan, batch, seq_len, xf, cf, text_embed, tf, drop_audio_cond, mk, out):
+        _lib.check(lib.f5_dit_forward(plan, batch, seq_len, _lib.ptr(xf), _lib.ptr(cf), _lib.ptr(text_embed), _lib.ptr(tf),
+                                      drop_audio_cond, _lib.ptr(mk), _lib.ptr(out), _lib.stream_ptr()), "dit_forward")
 
     # ------------------------------------------------------------------ whole-loop entry used by CFM.sample
     def native_sample(self, cond, text, lens, durations, y0, tgrid, steps, cfg_strength, method="euler", use_mask=True,

@@ -33,7 +33,7 @@ extern "C" {
 /* the library is built with -fvisibility=hidden: only the entry points declared here are exported */
 #define F5_API __attribute__((visibility("default")))
 
-#define F5HIP_VERSION 300 /* 0.3.0 */
+#define F5HIP_VERSION 301 /* 0.3.1 */
 
 /* error codes */
 #define F5_OK 0
@@ -83,6 +83,9 @@ typedef struct f5_dit_config {
 #define F5_BACKBONE_DIT 0   /* model/backbones/dit.py:103   (F5-TTS) */
 #define F5_BACKBONE_UNETT 1 /* model/backbones/unett.py:103 (E2-TTS: flat U-Net transformer; tensor names = UNetT.state_dict(): layers.<i>.{0.weight,
                              * 1.g, 2.to_q|to_k|to_v|to_out.0.{weight,bias}, 3.g, 4.ff.0.0.*, 4.ff.2.*}, norm_out.g; depth must be even) */
+#define F5_BACKBONE_MMDIT 2 /* model/backbones/mmdit.py:85  (SD3-style joint text / audio blocks; tensor names = MMDiT.state_dict(): audio_embed.*,
+                             * transformer_blocks.<i>.{attn_norm_x, attn_norm_c}.linear.*, .attn.{to_q,to_k,to_v}[_c].*, .attn.to_out.0.*, .attn.to_out_c.*,
+                             * .ff_x.ff.*, .ff_c.ff.* (no to_out_c / ff_c in the last, context_pre_only block); text_dim must equal dim, conv_layers 0) */
 #define F5_SKIP_CONCAT 0 /* x = Linear(2 dim -> dim, no bias)(cat(x, skip)) in the second half of the layers (default) */
 #define F5_SKIP_ADD 1
 #define F5_SKIP_NONE 2
@@ -142,6 +145,11 @@ F5_API int f5_text_embed(f5_plan_t p, int B, int N, const int32_t* text, int nt,
  *   cond/uncond cache of dit.py:202-210); time dev f32 [B]; mask dev u8 [B, N] or NULL; out dev f32 [B, N, mel]. */
 F5_API int f5_dit_forward(f5_plan_t p, int B, int N, const float* x, const float* cond, const float* text_embed,
                    const float* time, int drop_audio_cond, const uint8_t* mask, float* out, f5_stream_t stream);
+
+/* MMDiT.forward (mmdit.py:146-190) for one branch: as f5_dit_forward, with the text stream at its own length --
+ *   text_embed dev f32 [B, nt, dim] (f5_text_embed on an F5_BACKBONE_MMDIT plan writes [B, nt, dim] and ignores N), nt <= the plan's max_seq. */
+F5_API int f5_mmdit_forward(f5_plan_t p, int B, int N, int nt, const float* x, const float* cond, const float* text_embed,
+                     const float* time, int drop_audio_cond, const uint8_t* mask, float* out, f5_stream_t stream);
 
 /* debug/parity taps: after the next f5_dit_forward / f5_sample evaluation, copy the named internal stage
  * (converted to f32, row-major [rows, cols]) into `dst` (dev f32).  Names: "t_emb", "input_embed",
