@@ -60,7 +60,7 @@ class F5TTSWrapper:
             model_cfg = yaml.safe_load(f)
         model_cls = getattr(_backbones, model_cfg["model"]["backbone"], None)  # plug point A (reference :134)
         if model_cls is None:
-            raise NotImplementedError(f"backbone {model_cfg['model']['backbone']} is not on the MI355X path (DiT and UNetT are; MMDiT is not built)")
+            raise NotImplementedError(f"backbone {model_cfg['model']['backbone']} is not on the MI355X path (DiT, UNetT and MMDiT are)")
         model_arc = dict(model_cfg["model"]["arch"])
         if precision is not None:
             model_arc["precision"] = precision

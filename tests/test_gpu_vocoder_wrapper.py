@@ -108,25 +108,29 @@ def _write_tiny_assets(tmp, arch, V, W, vocos_hp, VW, backbone="DiT"):
     return cfg_path, ckpt, vdir, vocab
 
 
-def test_wrapper_with_the_unett_backbone(tmp_path):
-    """plug point A through the facade: a config whose `model.backbone` is UNetT (the reference resolves f5_tts.model.<backbone>,
-    infer/f5tts_wrapper.py:134; configs/E2TTS_*.yaml) + an EMA checkpoint with UNetT's tensor names -> preprocess_reference -> generate();
-    the mel of the (single) chunk equals CFM.sample over the same backbone called directly."""
+@pytest.mark.parametrize("backbone", ["UNetT", "MMDiT"])
+def test_wrapper_with_the_other_backbones(tmp_path, backbone):
+    """plug point A through the facade: a config whose `model.backbone` is UNetT / MMDiT (the reference resolves f5_tts.model.<backbone>,
+    infer/f5tts_wrapper.py:134; configs/E2TTS_*.yaml) + an EMA checkpoint with that class's tensor names -> preprocess_reference -> generate()."""
     from eraxvif5tts_amd.infer import audio
     from eraxvif5tts_amd.infer.f5tts_wrapper import F5TTSWrapper
-    from eraxvif5tts_amd.model import UNetT
-    arch = dict(dim=128, depth=4, heads=2, ff_mult=2, pe_attn_head=1, text_mask_padding=False)
+    from eraxvif5tts_amd import model as _model
     V = 32
-    W = cpu_ref.random_unett_weights(arch, V, seed=45)
+    if backbone == "UNetT":
+        arch = dict(dim=128, depth=4, heads=2, ff_mult=2, pe_attn_head=1, text_mask_padding=False)
+        W = cpu_ref.random_unett_weights(arch, V, seed=45)
+    else:
+        arch = dict(dim=128, depth=3, heads=2, ff_mult=2, text_mask_padding=True)
+        W = cpu_ref.random_mmdit_weights(arch, V, seed=47)
     hp = dict(dim=64, intermediate_dim=128, num_layers=2)
     VW = cpu_ref.random_vocos_weights(seed=46, dim=64, inter=128, layers=2)
-    cfg_path, ckpt, vdir, vocab = _write_tiny_assets(str(tmp_path), arch, V, W, hp, VW, backbone="UNetT")
+    cfg_path, ckpt, vdir, vocab = _write_tiny_assets(str(tmp_path), arch, V, W, hp, VW, backbone=backbone)
     sr = 24000
     t = np.arange(int(2.0 * sr)) / sr
     ref_wav = os.path.join(str(tmp_path), "ref.wav")
     audio.write_wav(ref_wav, 0.2 * np.sin(2 * np.pi * 170 * t), sr)
     tts = F5TTSWrapper(model_name=cfg_path, ckpt_path=ckpt, vocab_file=vocab, use_local_vocoder=True, vocoder_path=vdir, precision="fp32")
-    assert isinstance(tts.model.transformer, UNetT)
+    assert type(tts.model.transformer) is getattr(_model, backbone)
     tts.preprocess_reference(ref_wav, "a steady tone")
     torch.manual_seed(3)
     wave, rate, spec = tts.generate("hello there.", nfe_step=3, return_numpy=True, return_spectrogram=True)
