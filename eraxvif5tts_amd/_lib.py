@@ -58,6 +58,7 @@ _PROTOS = {
     "f5_sample_finish": (_I, [_P, _P]),
     "f5_text_embed": (_I, [_P, _I, _I, _P, _I, _I, _P, _P]),
     "f5_dit_forward": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
+    "f5_sample_ragged": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, C.c_float, _I, _P, _P]),
     "f5_mmdit_forward": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "f5_plan_timing_begin": (_I, [_P, _I]),
     "f5_plan_timing_end": (_I, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int), _P]),

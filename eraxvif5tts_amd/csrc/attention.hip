@@ -7,12 +7,12 @@
 
 template <typename T>
 __global__ __launch_bounds__(256) void attn_ref_kernel(const T* __restrict__ qkv, int ldq, int inner, const uint8_t* __restrict__ mask,
-                                                       T* __restrict__ out, int ldo, int N, float scale) {
+                                                       T* __restrict__ out, int ldo, int N, int bs /* rows between batch items (N, or more: ragged sampler) */, float scale) {
     constexpr int D = 64, TQ = 64, TK = 64, LD = 65;
     __shared__ float Qs[TQ * LD], Ks[TK * LD], Vs[TK * LD], Ps[TQ * LD];
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * TQ;
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    const T* base = qkv + (size_t)b * N * ldq + h * D;
+    const T* base = qkv + (size_t)b * bs * ldq + h * D;
 
     for (int i = tid; i < TQ * D; i += 256) {
         const int r = i >> 6, d = i & 63;
@@ -102,26 +102,28 @@ __global__ __launch_bounds__(256) void attn_ref_kernel(const T* __restrict__ qkv
         if (q < N) {
             const float inv = l_i[i] > 0.f ? 1.0f / l_i[i] : 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) out[((size_t)b * N + q) * ldo + h * D + 4 * tx + j] = from_f32<T>(o[i][j] * inv);
+            for (int j = 0; j < 4; ++j) out[((size_t)b * bs + q) * ldo + h * D + 4 * tx + j] = from_f32<T>(o[i][j] * inv);
         }
     }
 }
 
-int launch_attention_fast(int B, int N, int H, const void* qkv, int ldq, const uint8_t* mask, void* out, int ldo, hipStream_t stream);  // attention_fast.hip
+int launch_attention_fast(int B, int N, int H, const void* qkv, int ldq, const uint8_t* mask, void* out, int ldo, hipStream_t stream, int bstride);  // attention_fast.hip
 
 int launch_attention(int precision, int kernel_kind, int B, int N, int H, const void* qkv, int ldq, const uint8_t* mask, void* out, int ldo,
-                     hipStream_t stream) {
+                     hipStream_t stream, int bstride) {
     if (B <= 0 || N <= 0 || H <= 0) return 0;
+    if (bstride <= 0) bstride = N;
+    if (bstride < N || (bstride != N && mask)) return f5_fail(F5_EINVAL, "attention: batch stride below N, or a key mask with a batch stride");
     if (kernel_kind == 1) {
         if (!attention_fast_supported(precision, N, H)) return f5_fail(F5_EINVAL, "attention: tuned kernel does not support this problem");
-        return launch_attention_fast(B, N, H, qkv, ldq, mask, out, ldo, stream);
+        return launch_attention_fast(B, N, H, qkv, ldq, mask, out, ldo, stream, bstride);
     }
     const float scale = 0.125f;  // 1/sqrt(64) (SDPA default scale, modules.py:490)
     dim3 grid(cdiv(N, 64), H, B), block(256);
     if (precision == F5_PREC_BF16)
-        hipLaunchKernelGGL((attn_ref_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)qkv, ldq, H * 64, mask, (bf16_t*)out, ldo, N, scale);
+        hipLaunchKernelGGL((attn_ref_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)qkv, ldq, H * 64, mask, (bf16_t*)out, ldo, N, bstride, scale);
     else
-        hipLaunchKernelGGL((attn_ref_kernel<float>), grid, block, 0, stream, (const float*)qkv, ldq, H * 64, mask, (float*)out, ldo, N, scale);
+        hipLaunchKernelGGL((attn_ref_kernel<float>), grid, block, 0, stream, (const float*)qkv, ldq, H * 64, mask, (float*)out, ldo, N, bstride, scale);
     F5_LAUNCH_CHECK();
     return 0;
 }

@@ -56,7 +56,8 @@ __device__ __forceinline__ void stagger_delay(int id, int lo, int hi, int ticks)
 //     steady state (-8 % on its own).
 template <bool MASKED>
 __global__ __launch_bounds__(256, 2) void attn_wide_kernel(const bf16_t* __restrict__ qkv, int ldq, int inner, const uint8_t* __restrict__ mask,
-                                                           bf16_t* __restrict__ out, int ldo, int N, float c, int stagger_lo, int stagger_hi, int stagger_ticks) {
+                                                           bf16_t* __restrict__ out, int ldo, int N, int bs /* rows between batch items */, float c, int stagger_lo,
+                                                           int stagger_hi, int stagger_ticks) {
     constexpr int KT = 64, QB = 2, TB = KT * 128, NBUF = 3, BUF = 2 * TB, WAVES = 4;
     constexpr int PCS = 8 / WAVES;  // K (and V) pieces per wave per tile
     constexpr int MAXT = 128;  // tiles whose key validity bits fit the LDS table (launcher: N <= 64 * MAXT when masked)
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void attn_wide_kernel(const bf16_t* __restr
     }
     const int b = bh / gridDim.y, head = bh - b * gridDim.y, q0 = qblk * (32 * QB * WAVES) + wave * (32 * QB);
     const int r = lane & 31, h = lane >> 5;
-    const bf16_t* base = qkv + (size_t)b * N * ldq + head * 64;
+    const bf16_t* base = qkv + (size_t)b * bs * ldq + head * 64;
     const bf16_t* kbase = base + inner;
     const bf16_t* vbase = base + 2 * inner;
     const int nt = (N + KT - 1) / KT;
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void attn_wide_kernel(const bf16_t* __restr
             }
     }
     {
-        bf16_t* obase = out + ((size_t)b * N + q0) * ldo + head * 64;
+        bf16_t* obase = out + ((size_t)b * bs + q0) * ldo + head * 64;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int row = 8 * k + (lane_e >> 3), chunk = lane_e & 7;
@@ -776,9 +777,9 @@ int g_attn_persist = 0;
 
 bool attention_fast_supported(int precision, int N, int H) { return precision == F5_PREC_BF16 && N >= 1 && H >= 1; }
 
-int launch_attention_pipe(int waves, int B, int N, int H, const void* qkv, int ldq, const uint8_t* mask, void* out, int ldo, hipStream_t stream);  // attention_pipe.hip
+int launch_attention_pipe(int waves, int B, int N, int H, const void* qkv, int ldq, const uint8_t* mask, void* out, int ldo, hipStream_t stream, int bstride);  // attention_pipe.hip
 
-int launch_attention_fast(int B, int N, int H, const void* qkv, int ldq, const uint8_t* mask, void* out, int ldo, hipStream_t stream) {
+int launch_attention_fast(int B, int N, int H, const void* qkv, int ldq, const uint8_t* mask, void* out, int ldo, hipStream_t stream, int bstride) {
     if ((ldq & 7) || (ldo & 7)) return f5_fail(F5_EINVAL, "attention_fast: ldq and ldo must be multiples of 8");
     // 256 queries per workgroup need at least one workgroup per CU to pay; below that (single-utterance serving) the 128-query
     // workgroups of the pipelined kernel fill the chip better (B = 1: 17 vs 23 us)
@@ -791,7 +792,8 @@ int launch_attention_fast(int B, int N, int H, const void* qkv, int ldq, const u
     bool wide = g_attn_variant == 2 || g_attn_variant == 6 || (g_attn_variant == 0 && (long)B * H * cdiv(N, 256) >= cus);
     if (masked && N > 64 * 128) wide = false;  // the wide kernel's table of key validity bits holds 128 tiles
     if ((size_t)N * (size_t)ldq * 2u >= (1ull << 32)) wide = false;  // its per-lane key offsets are 32-bit
-    if (!wide) return launch_attention_pipe(4, B, N, H, qkv, ldq, mask, out, ldo, stream);
+    if ((size_t)bstride * (size_t)ldq * 2u >= (1ull << 32)) wide = false;
+    if (!wide) return launch_attention_pipe(4, B, N, H, qkv, ldq, mask, out, ldo, stream, bstride);
     const float c = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
     // persistent grid (two workgroups per CU walking items, K/V ring and Q prefetch running on across items): unmasked whole 256-query blocks,
     // at least three key tiles per item (the Q prefetch and the output stores are retired by the second tile's counted wait) and at least
@@ -800,7 +802,7 @@ int launch_attention_fast(int B, int N, int H, const void* qkv, int ldq, const u
     const long wgs = (long)B * H * cdiv(N, 256);
     const int stagger = (g_attn_stagger > 0 && wgs >= 4L * cus) ? g_attn_stagger * cdiv(N, 64) : 0;
     const long items = (long)B * H * (N / 256);
-    const bool persist_shape = !masked && N % 256 == 0 && N / 64 >= 3 && items < (1L << 30);
+    const bool persist_shape = !masked && N % 256 == 0 && N / 64 >= 3 && items < (1L << 30) && bstride == N;
     if (persist_shape && (g_attn_variant == 6 || (g_attn_variant == 0 && g_attn_persist && items >= 4L * cus))) {
         const int G = (int)(items < 2L * cus ? items : 2L * cus);  // (items is a multiple of 8 whenever B * H is: the kernel's XCD-aware order applies)
         if (g_attn_stamp_buf)
@@ -814,9 +816,9 @@ int launch_attention_fast(int B, int N, int H, const void* qkv, int ldq, const u
     }
     dim3 grid(cdiv(N, 256), H, B);
     if (masked)
-        hipLaunchKernelGGL((attn_wide_kernel<true>), grid, dim3(256), 0, stream, (const bf16_t*)qkv, ldq, H * 64, mask, (bf16_t*)out, ldo, N, c, cus, 2 * cus, stagger);
+        hipLaunchKernelGGL((attn_wide_kernel<true>), grid, dim3(256), 0, stream, (const bf16_t*)qkv, ldq, H * 64, mask, (bf16_t*)out, ldo, N, bstride, c, cus, 2 * cus, stagger);
     else
-        hipLaunchKernelGGL((attn_wide_kernel<false>), grid, dim3(256), 0, stream, (const bf16_t*)qkv, ldq, H * 64, mask, (bf16_t*)out, ldo, N, c, cus, 2 * cus, stagger);
+        hipLaunchKernelGGL((attn_wide_kernel<false>), grid, dim3(256), 0, stream, (const bf16_t*)qkv, ldq, H * 64, mask, (bf16_t*)out, ldo, N, bstride, c, cus, 2 * cus, stagger);
     F5_LAUNCH_CHECK();
     return 0;
 }

@@ -67,7 +67,7 @@ __device__ __forceinline__ float sum_halves(float v) {
 template <bool MASKED, int WAVES, int ABL = 0, int WPE = 2>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void attn_pipe_kernel(const bf16_t* __restrict__ qkv, int ldq, int inner,
                                                                                  const uint8_t* __restrict__ mask, bf16_t* __restrict__ out,
-                                                                                 int ldo, int N, float c /* scale * log2(e) */) {
+                                                                                 int ldo, int N, int bs /* rows between batch items */, float c /* scale * log2(e) */) {
     constexpr int KT = 64;                // keys per tile
     constexpr int TB = KT * 128;          // 64 keys x 64 dims x 2 B
     constexpr int NTH = WAVES * 64, CH = 512 / NTH, QW = 32 * WAVES;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE,
     }
     const int b = bh / gridDim.y, head = bh - b * gridDim.y, q0 = qb * QW + wave * 32;
     const int r = lane & 31, h = lane >> 5;
-    const bf16_t* base = qkv + (size_t)b * N * ldq + head * 64;
+    const bf16_t* base = qkv + (size_t)b * bs * ldq + head * 64;
     const bf16_t* kbase = base + inner;
     const bf16_t* vbase = base + 2 * inner;
 
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE,
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     const int qrow = q0 + r;
     if (qrow < N) {
-        bf16_t* op = out + ((size_t)b * N + qrow) * ldo + head * 64 + 4 * h;
+        bf16_t* op = out + ((size_t)b * bs + qrow) * ldo + head * 64 + 4 * h;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -428,15 +428,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE,
 
 }  // namespace
 
-int launch_attention_pipe(int waves, int B, int N, int H, const void* qkv, int ldq, const uint8_t* mask, void* out, int ldo, hipStream_t stream) {
+int launch_attention_pipe(int waves, int B, int N, int H, const void* qkv, int ldq, const uint8_t* mask, void* out, int ldo, hipStream_t stream, int bstride) {
     if (waves != 4) return f5_fail(F5_EINVAL, "attention_pipe: the library instantiates the 4-wave (128 queries per workgroup) build only");
     const float c = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
     const bool masked = mask != nullptr || (N % 64) != 0;
     const dim3 grid(cdiv(N, 128), H, B);
     if (masked)
-        hipLaunchKernelGGL((attn_pipe_kernel<true, 4>), grid, dim3(256), 0, stream, (const bf16_t*)qkv, ldq, H * 64, mask, (bf16_t*)out, ldo, N, c);
+        hipLaunchKernelGGL((attn_pipe_kernel<true, 4>), grid, dim3(256), 0, stream, (const bf16_t*)qkv, ldq, H * 64, mask, (bf16_t*)out, ldo, N, bstride, c);
     else
-        hipLaunchKernelGGL((attn_pipe_kernel<false, 4>), grid, dim3(256), 0, stream, (const bf16_t*)qkv, ldq, H * 64, mask, (bf16_t*)out, ldo, N, c);
+        hipLaunchKernelGGL((attn_pipe_kernel<false, 4>), grid, dim3(256), 0, stream, (const bf16_t*)qkv, ldq, H * 64, mask, (bf16_t*)out, ldo, N, bstride, c);
     F5_LAUNCH_CHECK();
     return 0;
 }

@@ -478,6 +478,19 @@ int launch_joint_mask(const uint8_t* mask, int B, int N, int nt, uint8_t* dst, h
     F5_LAUNCH_CHECK();
     return 0;
 }
+// ---- ragged sampler (f5_sample_ragged): rows flagged 1 are the zero gaps between utterances, which stand for the position conv's zero padding
+__global__ __launch_bounds__(256) void zero_rows_kernel(uint4* __restrict__ x, int row_vec, const uint8_t* __restrict__ flags) {
+    const int row = blockIdx.x;
+    if (!flags[row]) return;
+    for (int c = threadIdx.x; c < row_vec; c += 256) x[(size_t)row * row_vec + c] = make_uint4(0u, 0u, 0u, 0u);
+}
+int launch_zero_rows(void* x, size_t row_bytes, int rows, const uint8_t* flags, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    if ((row_bytes & 15) || ((size_t)(uintptr_t)x & 15)) return f5_fail(F5_EINVAL, "zero_rows: rows must be multiples of 16 bytes");
+    hipLaunchKernelGGL(zero_rows_kernel, dim3(rows), dim3(256), 0, stream, (uint4*)x, (int)(row_bytes / 16), flags);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
 // x += y (skip_connect_type "add", unett.py:237-238); n % 4 == 0
 __global__ __launch_bounds__(256) void add_f32_kernel(float* __restrict__ x, const float* __restrict__ y, size_t nvec) {
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {

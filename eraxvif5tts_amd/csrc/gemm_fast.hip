@@ -295,8 +295,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
                 f32x4 v = acc[i][j0 + jj];  // bias: see init_acc
                 if constexpr (EPI == EPI_STORE_T || EPI == EPI_STORE_F32 || EPI == EPI_GATE_T || EPI == EPI_RESID) {
                     if (p.act == ACT_GELU_TANH) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fast_gelu_tanh(v[e]);
+                        v = epi_gelu_tanh4(v);
                     } else if (p.act == ACT_MISH) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fast_mish(v[e]);
@@ -309,15 +308,11 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
                     if (p.gate) v *= (p.gate_bstride != 0 ? aux[jj][i] : gate4[i]);
                     if (!keep[jj]) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 } else if constexpr (EPI == EPI_ROPE_T) {
-                    if (rope_wave) {  // x_transformers apply_rotary_pos_emb: adjacent pairs, fp32 math
-                        const f32x4 cs = aux[jj][i];
-                        v = f32x4{v[0] * cs[0] - v[1] * cs[1], v[1] * cs[0] + v[0] * cs[1], v[2] * cs[2] - v[3] * cs[3], v[3] * cs[2] + v[2] * cs[3]};
-                    }
+                    if (rope_wave) v = epi_rope4(v, aux[jj][i]);  // x_transformers apply_rotary_pos_emb: adjacent pairs, fp32 math
                 } else if constexpr (EPI == EPI_ADD2) {
                     v += aux[jj][i];
                 } else if constexpr (EPI == EPI_RESID) {
-                    if (p.gate) v *= gate4[i];
-                    v += aux[jj][i];
+                    v = p.gate ? epi_axpy4(v, gate4[i], aux[jj][i]) : v + aux[jj][i];
                 }
                 vals[i] = v;
             });
@@ -401,25 +396,14 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
             for (int i = 0; i < NI; ++i) {
                 f32x4 v = acc[i][j];
                 if constexpr (ACT == ACT_GELU_TANH) {
-                    constexpr float a = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
-                    const f32x4 u = v * __builtin_elementwise_fma(v * v, f32x4{a * 0.044715f, a * 0.044715f, a * 0.044715f, a * 0.044715f}, f32x4{a, a, a, a});
-                    f32x4 d;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) d[e] = __builtin_amdgcn_exp2f(u[e]);
-                    d = d + 1.0f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) d[e] = __builtin_amdgcn_rcpf(d[e]);
-                    v = v * d;
+                    v = epi_gelu_tanh4(v);
                 } else if constexpr (ACT == ACT_MISH) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fast_mish(v[e]);
                 }
                 if constexpr (EPI == EPI_GATE_T) v = v * gate4[i];
                 if constexpr (EPI == EPI_ROPE_T) {
-                    if (rope_wave) {
-                        const f32x4 cs = rp[j & 1][i];
-                        v = f32x4{v[0] * cs[0] - v[1] * cs[1], v[1] * cs[0] + v[0] * cs[1], v[2] * cs[2] - v[3] * cs[3], v[3] * cs[2] + v[2] * cs[3]};
-                    }
+                    if (rope_wave) v = epi_rope4(v, rp[j & 1][i]);
                 }
                 vals[i] = v;
             }
@@ -538,10 +522,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
                 x2 = widen_h(s0[0], s1[0]);
                 x3 = widen_h(s0[1], s1[1]);
             }
-            const f32x4 v0 = keep ? x0 + acc[0][j] * gate4[0] : x0;
-            const f32x4 v1 = keep ? x1 + acc[1][j] * gate4[1] : x1;
-            const f32x4 v2 = keep ? x2 + acc[2][j] * gate4[2] : x2;
-            const f32x4 v3 = keep ? x3 + acc[3][j] * gate4[3] : x3;
+            const f32x4 v0 = keep ? epi_axpy4(acc[0][j], gate4[0], x0) : x0;
+            const f32x4 v1 = keep ? epi_axpy4(acc[1][j], gate4[1], x1) : x1;
+            const f32x4 v2 = keep ? epi_axpy4(acc[2][j], gate4[2], x2) : x2;
+            const f32x4 v3 = keep ? epi_axpy4(acc[3][j], gate4[3], x3) : x3;
             const size_t jo = (size_t)16 * j;
             *reinterpret_cast<u32x4*>(hrow + jo * p.ldof) = pair_swap(to_h(v0), to_h(v1));
             *reinterpret_cast<u32x4*>(hrow + jo * p.ldof + 32) = pair_swap(to_h(v2), to_h(v3));

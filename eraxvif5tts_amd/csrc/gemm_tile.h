@@ -15,10 +15,34 @@ template <int N, int I = 0, typename F> __device__ __forceinline__ void static_f
 // exp2/rcp forms of the activations for the bf16 epilogues (the output rounding to bf16 dominates their ~1 ulp error):
 //   gelu_tanh(x) = 0.5 x (1 + tanh(u)) = x * sigmoid(2u),  u = sqrt(2/pi) (x + 0.044715 x^3)
 //   mish(x)      = x tanh(softplus(x)) = x * n / (n + 2),  n = e^x (e^x + 2)
+// The three epilogue expressions that contain a multiply feeding an add are written with EXPLICIT fused multiply-adds (epi_* below): the
+// whole-tile ("lean") and the ragged-tile ("generic") epilogues of gemm_fast.hip then round identically whatever the compiler's contraction
+// heuristics make of their different surroundings -- a token row's value must not depend on whether its 256-row tile is whole
+// (f5_sample_ragged: every utterance equals its own batch-1 call bit for bit, where it sits in other tiles).
 __device__ __forceinline__ float fast_gelu_tanh(float x) {
     const float a = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
-    const float u2 = x * (a + (a * 0.044715f) * (x * x));
-    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u2));
+    const float u2 = x * __builtin_fmaf(x * x, a * 0.044715f, a);
+    return x * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(u2) + 1.0f);
+}
+__device__ __forceinline__ f32x4 epi_gelu_tanh4(const f32x4& v) {  // elementwise fast_gelu_tanh, same operations in the same order
+    constexpr float a = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
+    const f32x4 u = v * __builtin_elementwise_fma(v * v, f32x4{a * 0.044715f, a * 0.044715f, a * 0.044715f, a * 0.044715f}, f32x4{a, a, a, a});
+    f32x4 d;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] = __builtin_amdgcn_exp2f(u[e]);
+    d = d + 1.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] = __builtin_amdgcn_rcpf(d[e]);
+    return v * d;
+}
+// x_transformers apply_rotary_pos_emb on two adjacent feature pairs; cs = (cos0, sin0, cos1, sin1)
+__device__ __forceinline__ f32x4 epi_rope4(const f32x4& v, const f32x4& cs) {
+    return f32x4{__builtin_fmaf(v[0], cs[0], -(v[1] * cs[1])), __builtin_fmaf(v[1], cs[0], v[0] * cs[1]),
+                     __builtin_fmaf(v[2], cs[2], -(v[3] * cs[3])), __builtin_fmaf(v[3], cs[2], v[2] * cs[3])};
+}
+// x + gate * branch
+__device__ __forceinline__ f32x4 epi_axpy4(const f32x4& branch, const f32x4& gate, const f32x4& x) {
+    return __builtin_elementwise_fma(branch, gate, x);
 }
 __device__ __forceinline__ float fast_mish(float x) {
     const float w = __builtin_amdgcn_exp2f(x * 1.4426950408889634f);

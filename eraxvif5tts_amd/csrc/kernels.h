@@ -5,8 +5,9 @@
 // ---- attention.hip
 // qkv: [B*N, 3*H*64] (q | k | v, token-major), mask u8 [B, N] or null, out [B*N, H*64]; activation dtype by precision.
 // kernel_kind 0: reference kernel (fp32 VALU math, any N); 1: tuned bf16 flash kernel (MFMA, in-register softmax).
+// bstride: token rows between consecutive batch items (0 = N; larger when the items sit in a longer concatenation, mask must then be null)
 int launch_attention(int precision, int kernel_kind, int B, int N, int H, const void* qkv, int ldq, const uint8_t* mask, void* out,
-                     int ldo, hipStream_t stream);
+                     int ldo, hipStream_t stream, int bstride = 0);
 bool attention_fast_supported(int precision, int N, int H);
 
 // ---- elementwise.hip
@@ -43,6 +44,8 @@ int launch_pack_time_token(int precision, const float* h, const void* branch, co
 int launch_pad_mask(const uint8_t* mask, int B, int N, uint8_t* dst, hipStream_t stream);                      // [B, N] -> [B, N + 1], leading 1
 int launch_drop_time_token(const float* src, int B, int N, int cols, float* dst, hipStream_t stream);          // [B * (N + 1), cols] -> [B * N, cols]
 int launch_add_f32(float* x, const float* y, size_t n, hipStream_t stream);                                    // x += y, n % 4 == 0
+// rows whose flag byte is 1 are zeroed (row_bytes a multiple of 16): the gaps between the utterances of a ragged sample()
+int launch_zero_rows(void* x, size_t row_bytes, int rows, const uint8_t* flags, hipStream_t stream);
 // ---- MMDiT (reference model/backbones/mmdit.py)
 // nb byte segments src + b * src_bstride -> dst + b * dst_bstride (everything a multiple of 16 bytes)
 int launch_copy_segments(const void* src, size_t src_bstride_bytes, void* dst, size_t dst_bstride_bytes, size_t seg_bytes, int nb, hipStream_t stream);

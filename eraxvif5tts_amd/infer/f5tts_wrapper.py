@@ -104,6 +104,10 @@ class F5TTSWrapper:
         # text chunks of one generate() call sampled concurrently (HIP streams); 1 = one after the other as the reference does.  Not a
         # constructor argument (the reference's signature is kept); set the attribute or F5HIP_CHUNK_STREAMS
         self.chunk_streams = int(os.environ.get("F5HIP_CHUNK_STREAMS", "4"))
+        # text chunks of one generate() call sampled as ONE ragged batch (libf5hip f5_sample_ragged): up to this many utterances per launch set
+        # (0 = off: chunks run one per stream as above).  Applies when every chunk has at least 256 frames (the row count from which a batch-1
+        # call takes the tuned kernels too, so both paths compute bit-identical mels).
+        self.ragged_chunks = int(os.environ.get("F5HIP_RAGGED_CHUNKS", "8"))
         self.nfe_step = 32
         self.cfg_strength = 2.0
         self.sway_sampling_coef = -1.0
@@ -186,14 +190,7 @@ class F5TTSWrapper:
         # of the 256 CUs, so the streams overlap.  Every chunk runs exactly the launches of the serial path -- same shapes, same kernels --
         # so its mel is bit-identical to the serial result; noise is drawn in chunk order either way.
         transformer = getattr(self.model, "transformer", None)
-        n_streams = 1
-        if torch.cuda.is_available() and hasattr(transformer, "finish_pending"):
-            n_streams = max(1, min(len(text_batches), int(self.chunk_streams)))
-        main = torch.cuda.current_stream() if n_streams > 1 else None
-        streams = self._chunk_stream_pool(n_streams) if n_streams > 1 else []
-        for st in streams:
-            st.wait_stream(main)  # the preprocessed prompt was produced on the caller's stream
-        mels = []
+        jobs = []  # (token list, frames asked for) per chunk -- host work of the reference's loop (:476-510), before any sampling
         for i, text_batch in enumerate(text_batches):
             local_speed = 0.3 if len(text_batch.encode("utf-8")) < 10 else speed
             final_text_list = convert_char_to_pinyin([self.ref_text + text_batch])
@@ -212,6 +209,35 @@ class F5TTSWrapper:
                 ref_text_len, gen_text_len = len(self.ref_text.encode("utf-8")), len(text_batch.encode("utf-8"))
                 duration = self.ref_audio_len + int(self.ref_audio_len / ref_text_len * gen_text_len / local_speed)
                 print(f"Calculated duration based on text ratio: {duration} frames")
+            jobs.append((final_text_list, int(duration)))
+
+        # Several chunks, each long enough for the tuned kernels: ONE ragged batch per group of chunks -- the utterances concatenated along the
+        # token axis, no padding to a common length, every chunk with the arithmetic of its own batch-1 call (bit-identical mels, same noise
+        # order).  A single-utterance sample() fills a fraction of the 256 CUs; the concatenation fills them.
+        ragged = (int(self.ragged_chunks) >= 2 and len(jobs) >= 2 and torch.cuda.is_available() and hasattr(transformer, "native_sample_ragged")
+                  and getattr(transformer, "BACKBONE", None) == 0 and min(d for _, d in jobs) >= 256 and max(d for _, d in jobs) <= 4096)
+        n_streams = 1
+        if not ragged and torch.cuda.is_available() and hasattr(transformer, "finish_pending"):
+            n_streams = max(1, min(len(text_batches), int(self.chunk_streams)))
+        main = torch.cuda.current_stream() if n_streams > 1 else None
+        streams = self._chunk_stream_pool(n_streams) if n_streams > 1 else []
+        for st in streams:
+            st.wait_stream(main)  # the preprocessed prompt was produced on the caller's stream
+        mels = []
+        if ragged:
+            group, rows = [], 0
+            groups = [group]
+            for job in jobs:
+                if group and (len(group) >= int(self.ragged_chunks) or rows + job[1] > 16384):
+                    group, rows = [], 0
+                    groups.append(group)
+                group.append(job)
+                rows += job[1]
+            with torch.inference_mode():
+                for group in groups:
+                    mels += self.model.sample_ragged(self.ref_audio_processed, [j[0][0] for j in group], [j[1] for j in group], steps=nfe_step,
+                                                     cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef)
+        for i, (final_text_list, duration) in enumerate(jobs if not ragged else []):
             with torch.inference_mode():
                 if n_streams > 1:
                     with torch.cuda.stream(streams[i % n_streams]):

@@ -293,6 +293,34 @@ class DiT(nn.Module):
         self._report_fallback(lib, plan)
         return out, traj
 
+    def native_sample_ragged(self, cond_cat, text, lens, frames, y0_cat, tgrid, steps, cfg_strength, method="euler"):
+        """Utterances of different frame counts in ONE set of launches (include/f5hip.h: f5_sample_ragged).  cond_cat / y0_cat f32
+        [sum(frames), mel] (the utterances one after the other), text int [B, nt] (-1 padded), lens int [B], frames list of ints.
+        Returns out_cat [sum(frames), mel]; every utterance's rows equal its own batch-1 native_sample()."""
+        lib = _lib.load()
+        if self.BACKBONE != _lib.F5_BACKBONE_DIT:
+            raise NotImplementedError("ragged sampling is built for the DiT backbone")
+        B = len(frames)
+        evals = steps * (2 if method == "midpoint" else 1)
+        seq = max(max(frames), int(text.shape[1])) + 32  # (rows per utterance incl. its zero gap, rounded: <= seq_cap of plan())
+        plan = self.plan(B, seq, evals)
+        dev = "cuda"
+        cond_cat = cond_cat.to(device=dev, dtype=torch.float32).contiguous()
+        y0_cat = y0_cat.to(device=dev, dtype=torch.float32).contiguous()
+        ids = text.to(device=dev, dtype=torch.int32).contiguous()
+        lens32 = lens.to(device=dev, dtype=torch.int32).contiguous()
+        fr = torch.tensor([int(f) for f in frames], dtype=torch.int32)
+        assert cond_cat.shape[0] == int(fr.sum()) == y0_cat.shape[0]
+        tg = tgrid.detach().to("cpu", torch.float32).contiguous()
+        out = torch.empty_like(cond_cat)
+        meth = {"euler": _lib.F5_ODE_EULER, "midpoint": _lib.F5_ODE_MIDPOINT}[method]
+        _lib.check(lib.f5_plan_set_option(plan, b"residual_guard", 1), "plan_set_option")
+        _lib.check(lib.f5_sample_ragged(plan, B, C.c_void_p(fr.data_ptr()), _lib.ptr(cond_cat), _lib.ptr(ids), ids.shape[1], _lib.ptr(lens32),
+                                        _lib.ptr(y0_cat), C.c_void_p(tg.data_ptr()), steps, float(cfg_strength), meth, _lib.ptr(out),
+                                        _lib.stream_ptr()), "sample_ragged")
+        self._report_fallback(lib, plan)
+        return out
+
     def finish_pending(self):
         """Complete every sample() issued with defer_guard=True: synchronise its stream, read the range-guard flag and let the library repeat
         the loop with fp32 residual storage if it was raised (the outputs are rewritten in place).  Returns the number of calls finished."""

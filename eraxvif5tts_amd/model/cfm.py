@@ -121,6 +121,53 @@ class CFM(nn.Module):
             out = vocoder(out)
         return out, trajectory
 
+    @torch.no_grad()
+    def sample_ragged(self, cond, texts, durations, *, lens=None, steps=32, cfg_strength=1.0, sway_sampling_coef=None, seed=None,
+                      max_duration=4096, y0s=None):
+        """``sample()`` for several texts over ONE prompt, each with its own duration, in one set of kernel launches without padding the
+        utterances to a common length (libf5hip ``f5_sample_ragged``).  Equivalent to ``[sample(cond, [t], d)[0] for t, d in zip(texts,
+        durations)]`` -- the reference's batch-1 arithmetic per utterance (cfm.py:82-208 with batch = 1: no key mask), noise drawn in the
+        same order -- and returns that list ([1, N_i, mel] each).  cond: mel [1, nc, mel] or raw wave [1, nw]; texts: list of str / list of
+        token lists; durations: list of ints."""
+        self.eval()
+        native = getattr(self.transformer, "native_sample_ragged", None)
+        if native is None:
+            raise NotImplementedError("the backbone has no ragged sampler")
+        if cond.ndim == 2:  # raw wave
+            cond = self.mel_spec(cond).permute(0, 2, 1)
+        cond = cond.to(next(self.parameters()).dtype)
+        assert cond.shape[0] == 1 and cond.shape[-1] == self.num_channels
+        cond_seq_len, device = cond.shape[1], cond.device
+        nutt = len(texts)
+        if not exists(lens):
+            lens = torch.full((nutt,), cond_seq_len, device=device, dtype=torch.long)
+        if isinstance(texts, torch.Tensor):  # token ids [B, nt], -1 padded
+            text = texts.to(device)
+        elif len(texts) and isinstance(texts[0], torch.Tensor):  # one id row per utterance
+            text = pad_sequence([x.reshape(-1) for x in texts], padding_value=-1, batch_first=True).to(device)
+        elif exists(self.vocab_char_map):
+            text = list_str_to_idx(list(texts), self.vocab_char_map).to(device)
+        else:
+            text = list_str_to_tensor(list(texts)).to(device)
+        duration = torch.tensor([int(d) for d in durations], device=device, dtype=torch.long)
+        duration = torch.maximum(torch.maximum((text != -1).sum(dim=-1), lens) + 1, duration).clamp(max=max_duration)  # cfm.py:127-131
+        frames = [int(d) for d in duration]
+        conds, noises = [], []
+        for i, n in enumerate(frames):
+            conds.append(F.pad(cond[0], (0, 0, 0, n - cond_seq_len), value=0.0))
+            if y0s is not None:
+                noises.append(y0s[i].reshape(n, self.num_channels).to(device=device, dtype=cond.dtype))
+            else:
+                if exists(seed):
+                    torch.manual_seed(seed)
+                noises.append(torch.randn(n, self.num_channels, device=self.device, dtype=cond.dtype))
+        t = torch.linspace(0, 1, steps + 1, device=self.device, dtype=cond.dtype)
+        if sway_sampling_coef is not None:
+            t = t + sway_sampling_coef * (torch.cos(torch.pi / 2 * t) - 1 + t)
+        out = native(torch.cat(conds), text, lens, frames, torch.cat(noises), t, steps, cfg_strength, method=self.odeint_kwargs.get("method", "euler"))
+        self.transformer.clear_cache()
+        return [o.unsqueeze(0).to(cond.dtype) for o in torch.split(out, frames)]
+
     def _sample_python(self, step_cond, cond, cond_mask, text, mask, y0, t, cfg_strength, method, return_trajectory):
         """Generic driver over ``transformer(...)`` calls (non-native backbones, edit_mask): same fixed-grid update rules."""
         def fn(tt, x):

@@ -137,6 +137,16 @@ F5_API int f5_sample(f5_plan_t p, int B, int N, const float* cond, const int32_t
  * it was raised, repeats the loop with fp32 residual storage and rewrites the outputs; it is a no-op when nothing is pending. */
 F5_API int f5_sample_finish(f5_plan_t p, f5_stream_t stream);
 
+/* The same ODE loop over B utterances of DIFFERENT frame counts in one set of launches -- no padding to a common length, no key mask:
+ * what F5TTSWrapper.generate needs for the text chunks of one call (the reference samples them one after the other at batch 1,
+ * infer/f5tts_wrapper.py:476-533; a batch-1 sample() has mask = None, model/cfm.py:152-155).  Each utterance gets the arithmetic of its own
+ * batch-1 f5_sample call: bit-identical output whenever both calls take the tuned kernels (every frames_host[i] >= 256, bf16 mode) or both the
+ * fp32 mode's.  frames_host: host int32 [B]; cond, y0, out: dev f32 [sum(frames), mel], the utterances one after the other; text dev int32
+ * [B, nt] (-1 padded); lens dev int32 [B] (prompt frames); no trajectory, no hipGraph (shapes rarely recur); DiT backbone only.
+ * Plan capacity: sum(frames_i + 16, each rounded up to 16) <= max_batch * max_seq, every frames_i and nt <= max_seq, B <= max_batch. */
+F5_API int f5_sample_ragged(f5_plan_t p, int B, const int32_t* frames_host, const float* cond, const int32_t* text, int nt, const int32_t* lens,
+                     const float* y0, const float* tgrid_host, int steps, float cfg_strength, int ode_method, float* out, f5_stream_t stream);
+
 /* TextEmbedding.forward (dit.py:49-79): text ids [B, nt] (-1 padded) -> dev f32 [B, N, text_dim] */
 F5_API int f5_text_embed(f5_plan_t p, int B, int N, const int32_t* text, int nt, int drop_text, float* out, f5_stream_t stream);
 

@@ -411,3 +411,48 @@ def test_concurrent_chunks_equal_serial_chunks_and_are_faster():
     ts, tc = min(times["serial"]), min(times["concurrent"])
     print(f"4 chunks ({durs} frames, NFE 8): serial {ts * 1e3:.1f} ms, concurrent on 4 streams {tc * 1e3:.1f} ms -> {ts / tc:.2f}x")
     assert tc < ts / 1.3
+
+
+def test_ragged_chunks_equal_serial_chunks_and_are_faster():
+    """the text chunks of one generate() call as ONE ragged batch (include/f5hip.h: f5_sample_ragged) -- four utterances
+    of different lengths concatenated along the token axis, no padding to a common length, no key mask -- against the reference's order,
+    four batch-1 sample() calls one after the other (infer/f5tts_wrapper.py:476-533, cfm.py:152-155).  F5TTS_Base, NFE 8, bf16 mode.  Every
+    utterance must come out bit-identical to its own batch-1 call, and the ragged form must be clearly faster."""
+    import time
+
+    import bench
+    from eraxvif5tts_amd.model import CFM, DiT
+    torch.manual_seed(1234)
+    model = bench.synth_weights(DiT(**bench.BASE_ARCH, text_num_embeds=bench.VOCAB, mel_dim=100, precision="bf16"), seed=0)
+    cfm = CFM(transformer=model, mel_spec_kwargs={"mel_spec_type": "vocos"}).cuda()
+    g = torch.Generator().manual_seed(31)
+    n_ref = 300
+    cond = (torch.randn(1, n_ref, 100, generator=g) * 2 - 3).clamp(math.log(1e-5), 3.0).cuda()
+    durs = [760, 1010, 900, 1180]
+    texts = [torch.randint(0, bench.VOCAB, (1, d // 7), generator=g).cuda() for d in durs]
+    y0s = [torch.randn(1, d, 100, generator=g).cuda() for d in durs]
+    kw = dict(steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0)
+
+    def serial():
+        return [cfm.sample(cond=cond, text=t, duration=d, y0=y, return_trajectory=False, use_graph=False, **kw)[0] for t, d, y in zip(texts, durs, y0s)]
+
+    def ragged():
+        return cfm.sample_ragged(cond, texts, durs, y0s=y0s, **kw)
+
+    ref = serial()
+    got = ragged()
+    torch.cuda.synchronize()
+    assert model.residual_fallbacks() == 0
+    for a, b, d in zip(got, ref, durs):
+        assert a.shape == (1, d, 100) and torch.isfinite(a).all()
+        assert torch.equal(a, b), float((a - b).abs().max())
+    times = {}
+    for name, fn in (("serial", serial), ("ragged", ragged), ("serial", serial), ("ragged", ragged)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        times.setdefault(name, []).append(time.perf_counter() - t0)
+    ts, tr = min(times["serial"]), min(times["ragged"])
+    print(f"4 chunks ({durs} frames, NFE 8): serial {ts * 1e3:.1f} ms, one ragged batch {tr * 1e3:.1f} ms -> {ts / tr:.2f}x")
+    assert tr < ts / 1.5

@@ -340,8 +340,13 @@ def test_generate_long_form_chunks_and_cross_fade(tmp_path):
     blend = first[-n:] * np.linspace(1, 0, n) + second[:n] * np.linspace(0, 1, n)
     assert np.allclose(faded[lens[0] - n: lens[0]], blend, atol=1e-6) and np.array_equal(faded[: lens[0] - n], first[:-n])
     assert np.isfinite(faded).all()
-    # the chunks of a call are sampled concurrently on HIP streams by default; one after the other (the reference's order) gives the same samples
-    assert tts.chunk_streams > 1
+    # the chunks of a call are sampled as one ragged batch by default (every chunk here has >= 256 frames); one chunk per HIP stream, and one
+    # after the other (the reference's order), give the same samples
+    assert tts.ragged_chunks >= 2 and tts.chunk_streams > 1
+    tts.ragged_chunks = 0
+    torch.manual_seed(21)
+    streamed, _ = tts.generate(text, nfe_step=2, return_numpy=True)
+    assert np.array_equal(streamed, faded)
     tts.chunk_streams = 1
     torch.manual_seed(21)
     serial, _ = tts.generate(text, nfe_step=2, return_numpy=True)
