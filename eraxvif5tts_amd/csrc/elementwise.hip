@@ -478,6 +478,41 @@ int launch_joint_mask(const uint8_t* mask, int B, int N, int nt, uint8_t* dst, h
     F5_LAUNCH_CHECK();
     return 0;
 }
+// ---- qk_norm = "rms_norm" (reference model/modules.py:275-294, 391-396, 463-467): RMSNorm(dim_head = 64, eps 1e-6, learned weight) on the q
+// and k features of every head, then the rotary embedding on the first rope_heads heads -- in place on the q|k|v rows the projection stored
+// (the fused-RoPE GEMM epilogue is not used with this switch).  One wave per (token row, q|k part, head): lane = feature.
+template <typename T>
+__global__ __launch_bounds__(256) void qknorm_rope_kernel(T* __restrict__ qkv, int ldq, int inner, int heads, int rope_heads, const float* __restrict__ wq,
+                                                          const float* __restrict__ wk, const float* __restrict__ rope, int rows_per_batch, int rows) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x;
+    const int pos = row % rows_per_batch;
+    for (int item = wave; item < 2 * heads; item += 4) {
+        const int part = item / heads, h = item - part * heads;
+        T* px = qkv + (size_t)row * ldq + (size_t)part * inner + h * 64 + lane;
+        const float x = to_f32(*px);
+        float ss = x * x;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        float y = x * rsqrtf(ss * (1.0f / 64.0f) + 1e-6f) * (part == 0 ? wq : wk)[lane];
+        const float other = __shfl_xor(y, 1, 64);
+        if (h < rope_heads) {  // x_transformers apply_rotary_pos_emb, adjacent pairs (2j, 2j+1)
+            const float c = rope[((size_t)pos * 32 + (lane >> 1)) * 2], sn = rope[((size_t)pos * 32 + (lane >> 1)) * 2 + 1];
+            y = (lane & 1) ? __builtin_fmaf(y, c, other * sn) : __builtin_fmaf(y, c, -(other * sn));
+        }
+        *px = from_f32<T>(y);
+    }
+}
+int launch_qknorm_rope(int precision, void* qkv, int ldq, int rows, int inner, int heads, int rope_heads, const float* wq, const float* wk,
+                       const float* rope, int rows_per_batch, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    if (precision == F5_PREC_BF16)
+        hipLaunchKernelGGL((qknorm_rope_kernel<bf16_t>), dim3(rows), dim3(256), 0, stream, (bf16_t*)qkv, ldq, inner, heads, rope_heads, wq, wk, rope, rows_per_batch, rows);
+    else
+        hipLaunchKernelGGL((qknorm_rope_kernel<float>), dim3(rows), dim3(256), 0, stream, (float*)qkv, ldq, inner, heads, rope_heads, wq, wk, rope, rows_per_batch, rows);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
 // ---- ragged sampler (f5_sample_ragged): rows flagged 1 are the zero gaps between utterances, which stand for the position conv's zero padding
 __global__ __launch_bounds__(256) void zero_rows_kernel(uint4* __restrict__ x, int row_vec, const uint8_t* __restrict__ flags) {
     const int row = blockIdx.x;

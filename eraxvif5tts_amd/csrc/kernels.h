@@ -44,6 +44,9 @@ int launch_pack_time_token(int precision, const float* h, const void* branch, co
 int launch_pad_mask(const uint8_t* mask, int B, int N, uint8_t* dst, hipStream_t stream);                      // [B, N] -> [B, N + 1], leading 1
 int launch_drop_time_token(const float* src, int B, int N, int cols, float* dst, hipStream_t stream);          // [B * (N + 1), cols] -> [B * N, cols]
 int launch_add_f32(float* x, const float* y, size_t n, hipStream_t stream);                                    // x += y, n % 4 == 0
+// qk_norm "rms_norm" (modules.py:275-294) + RoPE in place on stored q|k|v rows [rows, ldq]; wq / wk f32 [64]; rope [pos][32][cos, sin]
+int launch_qknorm_rope(int precision, void* qkv, int ldq, int rows, int inner, int heads, int rope_heads, const float* wq, const float* wk,
+                       const float* rope, int rows_per_batch, hipStream_t stream);
 // rows whose flag byte is 1 are zeroed (row_bytes a multiple of 16): the gaps between the utterances of a ragged sample()
 int launch_zero_rows(void* x, size_t row_bytes, int rows, const uint8_t* flags, hipStream_t stream);
 // ---- MMDiT (reference model/backbones/mmdit.py)

@@ -28,6 +28,7 @@ struct BlockW {
     // UNetT layers (unett.py:139-171): skip projection [D, 2D] of the later half (concat type), RMSNorm gains
     void* w_skip = nullptr;
     float *g_attn = nullptr, *g_ff = nullptr;
+    float *w_qn = nullptr, *w_kn = nullptr;  // qk_norm = "rms_norm": RMSNorm(dim_head) weights of q and k (modules.py:394-396)
     // MMDiT blocks (modules.py:646-707): the text stream's own projections; absent (null) in the last, context_pre_only block except w_qkv_c
     void *w_qkv_c = nullptr, *w_o_c = nullptr, *w_ff1_c = nullptr, *w_ff2_c = nullptr;
     float *b_qkv_c = nullptr, *b_o_c = nullptr, *b_ff1_c = nullptr, *b_ff2_c = nullptr;
@@ -55,6 +56,7 @@ struct f5_model_s {
     void* w_out = nullptr;
     float* b_out = nullptr;
     float* g_out = nullptr;  // UNetT: norm_out.g
+    void* w_lskip = nullptr;  // long_skip_connection.weight [D, 2D] (dit.py:153)
     int td_pad = 0;          // text_dim rounded up to the GEMM's K granule (E2-TTS: text_dim = mel_dim = 100)
     int in_td = 0;           // text columns of the input projection (text_dim; 0 for MMDiT, whose text is a stream of its own)
     int text_pos_rows = 4096;  // rows of the sinusoidal table added to the text embedding (dit.py:41; 1024 mmdit.py:37)
@@ -175,8 +177,9 @@ extern "C" int f5_model_create(const f5_dit_config* c, f5_model_t* out) {
     if (!c || !out) return f5_fail(F5_EINVAL, "null argument");
     *out = nullptr;
     F5_TRY(f5_check_device());
-    if (c->qk_norm) return f5_fail(F5_ENOTSUP, "qk_norm is not implemented (null in every shipped config)");
-    if (c->long_skip) return f5_fail(F5_ENOTSUP, "long_skip_connection is not implemented (False in every shipped config)");
+    if ((c->qk_norm || c->long_skip) && c->backbone != F5_BACKBONE_DIT)
+        return f5_fail(F5_ENOTSUP, "qk_norm / long_skip_connection are implemented for the DiT backbone only (null / False in every shipped config)");
+    if (c->qk_norm != 0 && c->qk_norm != 1) return f5_fail(F5_EINVAL, "qk_norm: 0 (None) or 1 (\"rms_norm\", modules.py:394)");
     if (c->dim_head != 64) return f5_fail(F5_ENOTSUP, "dim_head=%d: only 64 is implemented", c->dim_head);
     if (c->dim <= 0 || c->dim % 128 != 0 || c->dim > 2048) return f5_fail(F5_EINVAL, "dim=%d must be a multiple of 128 (<= 2048)", c->dim);
     if (c->depth <= 0 || c->heads <= 0 || c->ff_inner <= 0 || c->ff_inner % 32 != 0) return f5_fail(F5_EINVAL, "bad depth/heads/ff_inner");
@@ -289,7 +292,12 @@ extern "C" int f5_model_create(const f5_dit_config* c, f5_model_t* out) {
             add_slot(s, p + "ff.ff.0.0.bias", {ff});
             add_slot(s, p + "ff.ff.2.weight", {D, ff});
             add_slot(s, p + "ff.ff.2.bias", {D});
+            if (c->qk_norm) {
+                add_slot(s, p + "attn.q_norm.weight", {64});
+                add_slot(s, p + "attn.k_norm.weight", {64});
+            }
         }
+        if (c->long_skip) add_slot(s, "long_skip_connection.weight", {D, 2 * D});
         add_slot(s, "norm_out.linear.weight", {2 * D, D});
         add_slot(s, "norm_out.linear.bias", {2 * D});
     }
@@ -502,6 +510,21 @@ extern "C" int f5_model_finalize(f5_model_t m) {
         F5_TRY(f5_upload_f32(A, H(m, pf + "ff.0.0.bias").data(), ff, &b.b_ff1));
         F5_TRY(f5_upload_t(A, P, H(m, pf + "ff.2.weight").data(), D * ff, &b.w_ff2));
         F5_TRY(f5_upload_f32(A, H(m, pf + "ff.2.bias").data(), D, &b.b_ff2));
+        if (c.qk_norm) {  // (half-split rotary layout: the features of the rope heads were re-ordered above, their norm weights follow)
+            for (int part = 0; part < 2; ++part) {
+                std::vector<float> w = H(m, pa + (part == 0 ? "q_norm.weight" : "k_norm.weight"));
+                if (c.rope_layout == F5_ROPE_HALF_SPLIT && m->rope_heads < c.heads)
+                    return f5_fail(F5_ENOTSUP, "qk_norm with the half-split rotary layout needs RoPE on every head (one weight vector serves all heads)");
+                if (c.rope_layout == F5_ROPE_HALF_SPLIT) {
+                    std::vector<float> o = w;
+                    for (int j = 0; j < 32; ++j) {
+                        w[2 * j] = o[j];
+                        w[2 * j + 1] = o[j + 32];
+                    }
+                }
+                F5_TRY(f5_upload_f32(A, w.data(), 64, part == 0 ? &b.w_qn : &b.w_kn));
+            }
+        }
         if (un) {
             F5_TRY(f5_upload_f32(A, H(m, p + "1.g").data(), D, &b.g_attn));
             F5_TRY(f5_upload_f32(A, H(m, p + "3.g").data(), D, &b.g_ff));
@@ -509,6 +532,7 @@ extern "C" int f5_model_finalize(f5_model_t m) {
         }
     }
     if (un) F5_TRY(f5_upload_f32(A, H(m, "norm_out.g").data(), D, &m->g_out));
+    if (c.long_skip) F5_TRY(f5_upload_t(A, P, H(m, "long_skip_connection.weight").data(), D * 2 * D, &m->w_lskip));
     {
         // proj_out rows padded to MELP so the tuned kernel can run it too (rows >= mel are zero)
         std::vector<float> w((size_t)MELP * D, 0.f), b(MELP, 0.f);
@@ -606,6 +630,11 @@ extern "C" int f5_plan_create(f5_model_t m, int max_batch, int max_seq, int max_
         if (c.backbone == F5_BACKBONE_DIT) {
             if ((rc = A.alloc_t(&p->rope_exp, (rows / 2 + 1) * 64))) break;
             if ((rc = A.alloc_t(&p->gapflag, rows))) break;
+        }
+        if (c.long_skip) {  // the input embedding kept for the end of the evaluation, and cat(x, residual) in the activation dtype
+            p->skips.assign(1, nullptr);
+            if ((rc = A.alloc_t(&p->skips[0], rows * D))) break;
+            if ((rc = A.alloc(&p->catT, rows * 2 * D * es))) break;
         }
         if (c.backbone == F5_BACKBONE_MMDIT) {
             const size_t rowsJ = (size_t)round_up(2 * bn * 2, 256);  // text length <= max_seq (f5_sample / f5_mmdit_forward check it)
@@ -782,7 +811,7 @@ int g_sync_evals = 0;  // diagnostic knob ("sync_evals"): an eager sample() sync
 // fp16 residual storage for this plan's evaluations (bf16 mode without stage taps; the plan option overrides the process-wide knob)
 static bool plan_res_f16(const f5_plan_s* p) {
     const bool want = p->res_f16 < 0 ? g_res_f16 != 0 : p->res_f16 != 0;
-    if (p->m->cfg.backbone != F5_BACKBONE_DIT) return false;  // (UNetT and MMDiT keep their streams in fp32)
+    if (p->m->cfg.backbone != F5_BACKBONE_DIT || p->m->cfg.long_skip) return false;  // (UNetT, MMDiT and the long-skip DiT keep fp32 streams)
     return want && p->taps.empty() && g_ln_defer && p->m->cfg.precision == F5_PREC_BF16 && p->xres16 && p->base16;
 }
 
@@ -893,7 +922,7 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
     // hoisted part of the input embedding included) -- the reference's own GPU path keeps the whole model, residual stream included, in
     // fp16 (utils_infer.py:184-193); arithmetic stays fp32 and the branches stay bf16.  Bytes per block of the two LayerNorm passes:
     // 1 408 -> 1 024 MiB at C2; of the input embedding 656 -> 400 MiB.
-    const bool defer = p->taps.empty() && g_ln_defer;
+    const bool defer = p->taps.empty() && g_ln_defer && !c.long_skip;  // (long skip: the stream after the input embedding is needed as a value)
     const bool r16 = plan_res_f16(p);
     unsigned* const sat = r16 ? p->sat_flag : nullptr;
     if (r16) {
@@ -947,6 +976,8 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
                                         wpf ? &pf1 : nullptr, sat, 1 | (l << 4));
         }));
         if (l == 0) F5_TRY(tap_f32(p, "input_embed", p->xres, D, rows, D, st));
+        if (l == 0 && c.long_skip)  // residual = x  (dit.py:217-218)
+            F5_HIP(hipMemcpyAsync(p->skips[0], p->xres, (size_t)rows * D * sizeof(float), hipMemcpyDeviceToDevice, st));
         if (l > 0) F5_TRY(tap_f32(p, "blk" + std::to_string(l - 1) + ".out", p->xres, D, rows, D, st));
         F5_TRY(tap_t(p, tn + ".n1", p->hT, D, rows, D, st));
         g = gp_zero();
@@ -959,7 +990,14 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         const int tiles_m = rows / 256, ncu = f5_cu_count();
         const bool split_v = P == F5_PREC_BF16 && p->gemm_kernel != 0 && rows % 256 == 0 && inner % 256 == 0 && (tiles_m * (2 * inner / 256)) % ncu == 0 &&
                              (tiles_m * (3 * inner / 256)) % ncu != 0 && tiles_m * (inner / 256) < ncu;
-        if (split_v) {
+        if (c.qk_norm) {  // q, k stored as projected; RMSNorm per head, then RoPE, in place (modules.py:463-475)
+            g.rope = nullptr;
+            g.rope_inner = g.rope_heads = 0;
+            F5_TRY(timed(p, F5_SITE_QKV, st, [&] {
+                const int rc = run_gemm(p, g, GEMM_DENSE, EPI_STORE_T, st);
+                return rc ? rc : launch_qknorm_rope(P, p->qkv, 3 * inner, rows, inner, c.heads, m->rope_heads, b.w_qn, b.w_kn, rg ? p->rope_exp : p->rope, N, st);
+            }));
+        } else if (split_v) {
             GemmParams gv = g;
             g.N = 2 * inner;
             gv.N = inner;
@@ -1039,6 +1077,16 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         F5_TRY(launch_layernorm_res(P, r16 ? p->xres16 : (const void*)p->xres, r16, r16 ? p->xres16 : (void*)p->xres, r16, D, rows, D, p->yT, D, nullptr,
                                     defer ? 2 : 1, mf, mf + D, mod_bstride, N, 1, p->hT, D, st, nullptr, sat, 3));
     F5_TRY(tap_f32(p, "blk" + std::to_string(c.depth - 1) + ".out", p->xres, D, rows, D, st));
+    if (c.long_skip) {  // x = long_skip_connection(cat(x, residual))  (dit.py:227-228), then the final AdaLN on it
+        const size_t es = f5_elem_size(P);
+        F5_TRY(launch_convert_pad(P, p->xres, D, rows, D, D, p->catT, 2 * D, st));
+        F5_TRY(launch_convert_pad(P, p->skips[0], D, rows, D, D, (char*)p->catT + (size_t)D * es, 2 * D, st));
+        g = gp_zero();
+        g.A = p->catT; g.lda = 2 * D; g.W = m->w_lskip; g.ldw = 2 * D; g.M = rows; g.N = D; g.K = 2 * D;
+        g.out_f = p->xres; g.ldof = D;
+        F5_TRY(run_gemm(p, g, GEMM_DENSE, EPI_STORE_F32, st));
+        F5_TRY(launch_layernorm(P, p->xres, D, rows, D, mf, mf + D, mod_bstride, N, 1, p->hT, D, st));
+    }
     F5_TRY(tap_t(p, "final_norm", p->hT, D, rows, D, st));
     g = gp_zero();
     g.A = p->hT; g.lda = D; g.W = m->w_out; g.ldw = D; g.M = rows; g.N = MELP; g.K = D;

@@ -73,23 +73,31 @@ class DiT(nn.Module):
                  text_dim=None, text_mask_padding=True, qk_norm=None, conv_layers=0, pe_attn_head=None,
                  long_skip_connection=False, checkpoint_activations=False, precision=None, rope_layout=None):
         super().__init__()
-        if long_skip_connection:
-            raise NotImplementedError("long_skip_connection is False in every shipped config and is not implemented")
+        self.long_skip = bool(long_skip_connection)  # dit.py:153: Linear(2 dim -> dim, no bias) on cat(x, input embedding) after the blocks
         self.checkpoint_activations = checkpoint_activations  # training-only knob; accepted and ignored
         self._setup(dim=dim, depth=depth, heads=heads, dim_head=dim_head, ff_mult=ff_mult, mel_dim=mel_dim, text_num_embeds=text_num_embeds,
                     text_dim=text_dim, text_mask_padding=text_mask_padding, qk_norm=qk_norm, conv_layers=conv_layers, pe_attn_head=pe_attn_head,
                     precision=precision, rope_layout=rope_layout)
 
     def _spec(self):
-        return _param_spec(self.dim, self.depth, self.heads, self.dim_head, self.ff_inner, self.mel_dim, self.text_num_embeds, self.text_dim,
+        spec = _param_spec(self.dim, self.depth, self.heads, self.dim_head, self.ff_inner, self.mel_dim, self.text_num_embeds, self.text_dim,
                            self.conv_layers)
+        if self.qk_norm == "rms_norm":  # modules.py:394-396: RMSNorm(dim_head, eps=1e-6) on q and k
+            for i in range(self.depth):
+                spec += [(f"transformer_blocks.{i}.attn.q_norm.weight", (self.dim_head,), "ones"), (f"transformer_blocks.{i}.attn.k_norm.weight", (self.dim_head,), "ones")]
+        if self.long_skip:
+            spec += [("long_skip_connection.weight", (self.dim, 2 * self.dim), "linear")]
+        return spec
 
     def _setup(self, *, dim, depth, heads, dim_head, ff_mult, mel_dim, text_num_embeds, text_dim, text_mask_padding, qk_norm, conv_layers,
                pe_attn_head, precision, rope_layout, skip_connect_type="concat"):
         if text_dim is None:
             text_dim = mel_dim
-        if qk_norm is not None:
-            raise NotImplementedError("qk_norm is null in every shipped config and is not implemented by the HIP kernels")
+        if qk_norm not in (None, "rms_norm"):
+            raise ValueError(f"Unimplemented qk_norm: {qk_norm}")  # modules.py:398
+        if (qk_norm is not None or getattr(self, "long_skip", False)) and self.BACKBONE != _lib.F5_BACKBONE_DIT:
+            raise NotImplementedError("qk_norm / long_skip_connection are built for the DiT backbone (null / False in every shipped config)")
+        self.qk_norm = qk_norm
         self.dim, self.depth, self.heads, self.dim_head = dim, depth, heads, dim_head
         self.ff_inner = int(dim * ff_mult)
         self.mel_dim, self.text_num_embeds, self.text_dim = mel_dim, text_num_embeds, text_dim
@@ -168,7 +176,8 @@ class DiT(nn.Module):
         cfg = _lib.DitConfig(dim=self.dim, depth=self.depth, heads=self.heads, dim_head=self.dim_head, ff_inner=self.ff_inner,
                              mel_dim=self.mel_dim, text_num_embeds=self.text_num_embeds, text_dim=self.text_dim,
                              conv_layers=self.conv_layers, text_mask_padding=int(self.text_mask_padding),
-                             pe_attn_head=self.pe_attn_head or 0, qk_norm=0, long_skip=0, precision=self.precision,
+                             pe_attn_head=self.pe_attn_head or 0, qk_norm=int(self.qk_norm == "rms_norm"),
+                             long_skip=int(getattr(self, "long_skip", False)), precision=self.precision,
                              rope_layout=self.rope_layout, backbone=self.BACKBONE, skip_connect=_lib.F5_SKIP[self.skip_connect_type])
         h = C.c_void_p()
         _lib.check(lib.f5_model_create(C.byref(cfg), C.byref(h)), "model_create")

@@ -172,6 +172,9 @@ def attention(W, pre, cfg, x, mask, ang):
     q = _lin(x, W[pre + "to_q.weight"], W[pre + "to_q.bias"]).view(b, n, h, dh).transpose(1, 2)
     k = _lin(x, W[pre + "to_k.weight"], W[pre + "to_k.bias"]).view(b, n, h, dh).transpose(1, 2)
     v = _lin(x, W[pre + "to_v.weight"], W[pre + "to_v.bias"]).view(b, n, h, dh).transpose(1, 2)
+    if cfg.get("qk_norm") == "rms_norm" and (pre + "q_norm.weight") in W:  # modules.py:275-294,394-396,463-467: RMSNorm(dim_head, eps 1e-6) per head, before RoPE
+        q = F.rms_norm(q, (dh,), weight=W[pre + "q_norm.weight"], eps=1e-6)
+        k = F.rms_norm(k, (dh,), weight=W[pre + "k_norm.weight"], eps=1e-6)
     pn = cfg.get("pe_attn_head", None)
     pn = h if pn is None else pn
     hs = cfg.get("rope_layout", "adjacent") == "half_split"
@@ -218,8 +221,11 @@ def dit_forward(W, cfg, x, cond, text, time, drop_audio_cond, drop_text, mask=No
     ang = rope_angles(n, cfg.get("dim_head", 64))
     if trace is not None:
         trace.update({"t_emb": t_emb, "text_embed": text_embed, "input_embed": h})
+    residual = h  # dit.py:217-218
     for i in range(cfg["depth"]):
         h = dit_block(W, i, cfg, h, t_emb, mask, ang, trace=trace)
+    if cfg.get("long_skip_connection", False):  # dit.py:153,227-228: Linear(2 dim -> dim, no bias) on cat(x, residual)
+        h = _lin(torch.cat([h, residual], dim=-1), W["long_skip_connection.weight"])
     emb = _lin(silu(t_emb), W["norm_out.linear.weight"], W["norm_out.linear.bias"])
     scale, shift = emb.chunk(2, dim=1)  # modules.py:333: (scale, shift) order
     h = _layernorm(h) * (1 + scale)[:, None] + shift[:, None]
@@ -698,6 +704,10 @@ def dit_param_shapes(cfg, vocab_size, mel_dim=100):
             s.update({p + f"attn.{nm}.weight": (inner, D), p + f"attn.{nm}.bias": (inner,)})
         s.update({p + "attn.to_out.0.weight": (D, inner), p + "attn.to_out.0.bias": (D,),
                   p + "ff.ff.0.0.weight": (ff, D), p + "ff.ff.0.0.bias": (ff,), p + "ff.ff.2.weight": (D, ff), p + "ff.ff.2.bias": (D,)})
+        if cfg.get("qk_norm") == "rms_norm":  # modules.py:394-396
+            s.update({p + "attn.q_norm.weight": (cfg.get("dim_head", 64),), p + "attn.k_norm.weight": (cfg.get("dim_head", 64),)})
+    if cfg.get("long_skip_connection", False):  # dit.py:153
+        s["long_skip_connection.weight"] = (D, 2 * D)
     s.update({"norm_out.linear.weight": (2 * D, D), "norm_out.linear.bias": (2 * D,),
               "proj_out.weight": (mel_dim, D), "proj_out.bias": (mel_dim,)})
     return s

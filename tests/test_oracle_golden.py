@@ -131,6 +131,24 @@ def test_true_size_e2tts_forward():
         assert rel_l2(out, z[key]) < 5e-5, key
 
 
+@pytest.mark.parametrize("tag", ["qk", "ls", "both"])
+def test_dit_constructor_switches_match_reference(tag):
+    """qk_norm = "rms_norm" (RMSNorm(dim_head, eps 1e-6) on q and k of every head before RoPE, modules.py:275-294,463-467) and
+    long_skip_connection = True (Linear(2 dim -> dim) on cat(x, input embedding) after the blocks, dit.py:153,217-228): the oracle's restatement
+    against vectors the reference's own DiT produced with the switch(es) on -- forward of both CFG branches and CFM.sample."""
+    import ast
+    z = load_golden("tiny_switches")
+    arch = ast.literal_eval(str(z[f"{tag}.arch"]))
+    W = cpu_ref.random_dit_weights(arch, int(z[f"{tag}.vocab"]), seed=int(z[f"{tag}.seed"]))
+    g = lambda k: torch.from_numpy(z[f"{tag}.{k}"])
+    for drop, key in ((False, "out_c"), (True, "out_u")):
+        out = cpu_ref.dit_forward(W, arch, g("x"), g("cond"), g("text"), g("t"), drop, drop, mask=g("mask"))
+        assert rel_l2(out, z[f"{tag}.{key}"]) < 2e-5, key
+    out, traj = cpu_ref.sample(W, arch, g("cond")[:, :16], g("text"), g("duration"), lens=g("lens"), steps=4, cfg_strength=2.0,
+                               sway_sampling_coef=-1.0, seed=5)
+    assert rel_l2(traj, z[f"{tag}.sample_traj"]) < 2e-5 and rel_l2(out, z[f"{tag}.sample_out"]) < 2e-5
+
+
 def _mmdit_case(z, tag):
     import ast
     arch = ast.literal_eval(str(z[f"{tag}.arch"]))
