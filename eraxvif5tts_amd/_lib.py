@@ -38,7 +38,8 @@ class MelConfig(C.Structure):
 
 class DurationWeights(C.Structure):  # struct f5_duration_weights
     _fields_ = [(n, C.c_void_p) for n in ("text_embed", "conv1_w", "conv1_b", "norm1_w", "norm1_b", "conv2_w", "conv2_b", "norm2_w", "norm2_b",
-                                          "proj_w", "proj_b")] + [(n, C.c_int32) for n in ("vocab_rows", "in_channels", "filter_channels", "kernel_size")]
+                                          "proj_w", "proj_b")] + [(n, C.c_int32) for n in ("vocab_rows", "in_channels", "filter_channels", "kernel_size")] + \
+               [("cond_w", C.c_void_p), ("cond_b", C.c_void_p), ("gin_channels", C.c_int32)]
 
 
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
@@ -67,6 +68,7 @@ _PROTOS = {
     "f5_plan_set_option": (_I, [_P, C.c_char_p, _I]),
     "f5_plan_get_option": (_I, [_P, C.c_char_p, C.POINTER(C.c_int)]),
     "f5_duration_predict": (_I, [C.POINTER(DurationWeights), _I, _I, _P, _I, _P, _P, _P, _P]),
+    "f5_duration_predict_g": (_I, [C.POINTER(DurationWeights), _I, _I, _P, _I, _P, _P, _I, _P, _P, _P]),
     "f5_op_linear": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
     "f5_op_linear_fused": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P]),
     "f5_op_layernorm_modulate": (_I, [_I, _I, _P, _P, _P, _P, _P]),

@@ -15,10 +15,12 @@ namespace {
 
 // out[b][f][t] = relu(bias[f] + sum_{c, j} w[f][c][j] * in(b, c, t + j - k/2));  in() = embedding gather (GATHER) or a [b, C, nt] buffer,
 // multiplied by mask[b][t'] and zero outside [0, nt).  One thread per (f, t); the weight row of f is shared by the block's threads.
+// cadd (GATHER only, may be null): the speaker conditioning cond(g) [b][C][g_nt], g_nt = 1 (one vector per utterance) or nt, added to the embedding.
 template <bool GATHER>
 __global__ __launch_bounds__(256) void dp_conv_relu_kernel(const float* __restrict__ in, const float* __restrict__ emb, const int32_t* __restrict__ tok,
                                                            int add_one, int vocab_rows, const int32_t* __restrict__ mask, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, int C, int F, int k, int nt, float* __restrict__ out) {
+                                                           const float* __restrict__ bias, int C, int F, int k, int nt, float* __restrict__ out,
+                                                           const float* __restrict__ cadd, int g_nt) {
     const int t = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y, b = blockIdx.z;
     if (t >= nt) return;
     const int pad = k / 2;
@@ -32,7 +34,12 @@ __global__ __launch_bounds__(256) void dp_conv_relu_kernel(const float* __restri
             int id = tok[(size_t)b * nt + ts] + add_one;
             id = id < 0 ? 0 : (id >= vocab_rows ? vocab_rows - 1 : id);
             const float* er = emb + (size_t)id * C;
-            for (int c = 0; c < C; ++c) acc = __builtin_fmaf(wr[(size_t)c * k], er[c], acc);
+            if (cadd) {
+                const float* gr = cadd + (size_t)b * C * g_nt + (g_nt == 1 ? 0 : ts);
+                for (int c = 0; c < C; ++c) acc = __builtin_fmaf(wr[(size_t)c * k], er[c] + gr[(size_t)c * g_nt], acc);
+            } else {
+                for (int c = 0; c < C; ++c) acc = __builtin_fmaf(wr[(size_t)c * k], er[c], acc);
+            }
         } else {
             const float* xr = in + (size_t)b * C * nt + ts;
             for (int c = 0; c < C; ++c) acc = __builtin_fmaf(wr[(size_t)c * k], xr[(size_t)c * nt], acc);
@@ -81,10 +88,25 @@ __global__ __launch_bounds__(256) void dp_proj_kernel(const float* __restrict__ 
     out[(size_t)b * nt + t] = mask[(size_t)b * nt + t] ? acc : 0.f;
 }
 
+// cond(g): Conv1d(gin -> C, kernel 1): out[b][c][t] = bias[c] + sum_j w[c][j] * g[b][j][t]   (duration_predictor.py:25-26,33-35)
+__global__ __launch_bounds__(256) void dp_cond_kernel(const float* __restrict__ g, const float* __restrict__ w, const float* __restrict__ bias, int gin, int C,
+                                                      int g_nt, float* __restrict__ out) {
+    const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (t >= g_nt) return;
+    float acc = bias[c];
+    for (int j = 0; j < gin; ++j) acc = __builtin_fmaf(w[(size_t)c * gin + j], g[((size_t)b * gin + j) * g_nt + t], acc);
+    out[((size_t)b * C + c) * g_nt + t] = acc;
+}
+
 }  // namespace
 
 extern "C" int f5_duration_predict(const f5_duration_weights* w, int batch, int nt, const int32_t* tokens, int add_one, const int32_t* mask,
                                    float* scratch, float* out, f5_stream_t stream) {
+    return f5_duration_predict_g(w, batch, nt, tokens, add_one, mask, nullptr, 0, scratch, out, stream);
+}
+
+extern "C" int f5_duration_predict_g(const f5_duration_weights* w, int batch, int nt, const int32_t* tokens, int add_one, const int32_t* mask,
+                                     const float* g, int g_nt, float* scratch, float* out, f5_stream_t stream) {
     F5_TRY(f5_check_device());
     if (!w || !tokens || !mask || !scratch || !out) return f5_fail(F5_EINVAL, "f5_duration_predict: null argument");
     if (batch <= 0 || nt <= 0 || w->in_channels <= 0 || w->filter_channels <= 0 || w->kernel_size <= 0 || (w->kernel_size & 1) == 0 || w->vocab_rows <= 0)
@@ -96,14 +118,23 @@ extern "C" int f5_duration_predict(const f5_duration_weights* w, int batch, int 
     const int C = w->in_channels, F = w->filter_channels, k = w->kernel_size;
     float* h1 = scratch;
     float* h2 = scratch + (size_t)batch * F * nt;
+    const float* cadd = nullptr;
+    if (g) {
+        if (w->gin_channels <= 0 || !w->cond_w || !w->cond_b) return f5_fail(F5_EINVAL, "f5_duration_predict_g: g given but the net has no cond layer (gin_channels = 0)");
+        if (g_nt != 1 && g_nt != nt) return f5_fail(F5_EINVAL, "f5_duration_predict_g: g must be [batch, gin, 1] or [batch, gin, nt]");
+        float* cbuf = scratch + (size_t)2 * batch * F * nt;
+        hipLaunchKernelGGL(dp_cond_kernel, dim3(cdiv(g_nt, 256), C, batch), dim3(256), 0, st, g, w->cond_w, w->cond_b, w->gin_channels, C, g_nt, cbuf);
+        F5_LAUNCH_CHECK();
+        cadd = cbuf;
+    }
     const dim3 cgrid(cdiv(nt, 256), F, batch);
     hipLaunchKernelGGL((dp_conv_relu_kernel<true>), cgrid, dim3(256), 0, st, (const float*)nullptr, w->text_embed, tokens, add_one, w->vocab_rows, mask,
-                       w->conv1_w, w->conv1_b, C, F, k, nt, h1);
+                       w->conv1_w, w->conv1_b, C, F, k, nt, h1, cadd, g_nt);
     F5_LAUNCH_CHECK();
     hipLaunchKernelGGL(dp_groupnorm_kernel, dim3(batch), dim3(256), 0, st, h1, w->norm1_w, w->norm1_b, mask, F, nt, 1e-5f);
     F5_LAUNCH_CHECK();
     hipLaunchKernelGGL((dp_conv_relu_kernel<false>), cgrid, dim3(256), 0, st, (const float*)h1, (const float*)nullptr, (const int32_t*)nullptr, 0, 0, mask,
-                       w->conv2_w, w->conv2_b, F, F, k, nt, h2);
+                       w->conv2_w, w->conv2_b, F, F, k, nt, h2, (const float*)nullptr, 0);
     F5_LAUNCH_CHECK();
     hipLaunchKernelGGL(dp_groupnorm_kernel, dim3(batch), dim3(256), 0, st, h2, w->norm2_w, w->norm2_b, mask, F, nt, 1e-5f);
     F5_LAUNCH_CHECK();

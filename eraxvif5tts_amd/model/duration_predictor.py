@@ -31,9 +31,8 @@ class DurationPredictor(nn.Module):
             self.cond = nn.Conv1d(gin_channels, in_channels, 1)
 
     def _run(self, x, x_mask, g, add_one):
-        if g is not None:
-            raise NotImplementedError("DurationPredictor: speaker conditioning `g` is not implemented on the HIP path "
-                                      "(F5TTSWrapper.calculate_duration_with_predictor never passes it)")
+        if g is not None and self.gin_channels == 0:
+            raise AttributeError("DurationPredictor: `g` given but the net was built with gin_channels = 0 (no `cond` layer, reference :25-26)")
         if self.training and self.p_dropout > 0:
             raise RuntimeError("DurationPredictor: inference only (call .eval(); Dropout is the identity there)")
         _lib.require_gpu()
@@ -48,12 +47,20 @@ class DurationPredictor(nn.Module):
         tensors = [f32(self.text_embed.weight), f32(self.conv_1.weight), f32(self.conv_1.bias), f32(self.norm_1.weight), f32(self.norm_1.bias),
                    f32(self.conv_2.weight), f32(self.conv_2.bias), f32(self.norm_2.weight), f32(self.norm_2.bias),
                    f32(self.proj.weight).reshape(-1), f32(self.proj.bias)]
-        w = _lib.DurationWeights(*[C.c_void_p(t.data_ptr()) for t in tensors], self.text_embed.num_embeddings, self.in_channels,
-                                 self.filter_channels, self.kernel_size)
-        scratch = torch.empty(2 * b * self.filter_channels * nt, device=dev, dtype=torch.float32)
+        gdev, g_nt = None, 0
+        if g is not None:  # x = x + self.cond(g)  (reference :33-35); g [b, gin, 1] or [b, gin, nt]
+            gdev = g.detach().to(device=dev, dtype=torch.float32).contiguous()
+            if gdev.ndim != 3 or gdev.shape[0] != b or gdev.shape[1] != self.gin_channels or gdev.shape[2] not in (1, nt):
+                raise ValueError(f"g must be [batch, gin_channels, 1 | nt], got {tuple(gdev.shape)}")
+            g_nt = int(gdev.shape[2])
+            tensors += [f32(self.cond.weight).reshape(self.in_channels, self.gin_channels), f32(self.cond.bias)]
+        ptrs = [C.c_void_p(t.data_ptr()) for t in tensors]
+        w = _lib.DurationWeights(*ptrs[:11], self.text_embed.num_embeddings, self.in_channels, self.filter_channels, self.kernel_size,
+                                 ptrs[11] if g is not None else None, ptrs[12] if g is not None else None, self.gin_channels if g is not None else 0)
+        scratch = torch.empty(2 * b * self.filter_channels * nt + b * self.in_channels * max(g_nt, 1), device=dev, dtype=torch.float32)
         out = torch.empty(b, nt, device=dev, dtype=torch.float32)
-        _lib.check(lib.f5_duration_predict(C.byref(w), b, nt, _lib.ptr(tok), add_one, _lib.ptr(msk), _lib.ptr(scratch), _lib.ptr(out),
-                                           _lib.stream_ptr()), "f5_duration_predict")
+        _lib.check(lib.f5_duration_predict_g(C.byref(w), b, nt, _lib.ptr(tok), add_one, _lib.ptr(msk), _lib.ptr(gdev), g_nt, _lib.ptr(scratch),
+                                             _lib.ptr(out), _lib.stream_ptr()), "f5_duration_predict")
         return out.unsqueeze(1)  # [b, 1, nt] like the reference
 
     def forward(self, x, x_mask, g=None):

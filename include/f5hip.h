@@ -200,15 +200,22 @@ F5_API int f5_plan_get_option(f5_plan_t p, const char* key, int* value);
  * Replaces DurationPredictor.forward / .phoneme_forward (reference model/duration_predictor.py:28-46 / :48-68) as called from
  * F5TTSWrapper.calculate_duration_with_predictor (infer/f5tts_wrapper.py:381-406).  All tensors f32 on the device, PyTorch layouts:
  *   text_embed [vocab_rows, in_channels]; conv1_w [filter, in_channels, k]; conv2_w [filter, filter, k]; norm*_w/b [filter];
- *   proj_w [filter] (the [1, filter, 1] Conv1d weight); proj_b [1].  gin_channels / g conditioning is not supported (the wrapper never passes g). */
+ *   proj_w [filter] (the [1, filter, 1] Conv1d weight); proj_b [1]; cond_w / cond_b of the optional speaker conditioning (f5_duration_predict_g). */
 typedef struct f5_duration_weights {
     const float *text_embed, *conv1_w, *conv1_b, *norm1_w, *norm1_b, *conv2_w, *conv2_b, *norm2_w, *norm2_b, *proj_w, *proj_b;
     int32_t vocab_rows, in_channels, filter_channels, kernel_size;
+    const float *cond_w, *cond_b; /* speaker conditioning Conv1d(gin -> in_channels, 1): [in_channels, gin] and [in_channels]; NULL when gin_channels = 0 */
+    int32_t gin_channels;
 } f5_duration_weights;
 /* tokens i32 [batch, nt] (pad -1), add_one = 1 for forward() (ids shifted so that 0 is the filler), 0 for phoneme_forward();
  * mask i32 [batch, nt] (1 = real token); scratch f32 [2 * batch * filter_channels * nt]; out f32 [batch, nt] = log-durations * mask. */
 F5_API int f5_duration_predict(const f5_duration_weights* w, int batch, int nt, const int32_t* tokens, int add_one, const int32_t* mask,
                         float* scratch, float* out, f5_stream_t stream);
+/* the same with the speaker conditioning of duration_predictor.py:33-35: x = embedding + cond(g), g dev f32 [batch, gin_channels, g_nt] with
+ * g_nt = 1 (one vector per utterance, broadcast over the tokens) or nt; scratch f32 [2 * batch * filter_channels * nt + batch * in_channels * g_nt];
+ * g = NULL is f5_duration_predict. */
+F5_API int f5_duration_predict_g(const f5_duration_weights* w, int batch, int nt, const int32_t* tokens, int add_one, const int32_t* mask,
+                          const float* g, int g_nt, float* scratch, float* out, f5_stream_t stream);
 
 /* ------------------------------------------------------------------ per-op entry points (parity tests, micro-benchmarks) */
 /* out[M,N] = A[M,K] @ W[N,K]^T + bias ; A/W/out f32 dev; computed through the precision's GEMM kernel

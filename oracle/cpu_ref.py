@@ -663,14 +663,17 @@ def vocos_decode(V, mel):
 
 
 # ----------------------------------------------------------------------------- duration predictor
-def duration_predictor(W, tokens, mask, add_one=True, prefix=""):
+def duration_predictor(W, tokens, mask, add_one=True, prefix="", g_cond=None):
     """DurationPredictor.forward (model/duration_predictor.py:28-46; phoneme_forward :48-68 with add_one=False):
     Embedding(tokens+1) -> [Conv1d(k, pad k//2)(x*mask) -> relu -> GroupNorm(1 group: over all channels AND positions, eps 1e-5)] x2
-    -> Conv1d(F->1, 1)(x*mask) * mask.  Dropout is the identity at inference.  tokens [b, nt] (pad -1), mask [b, nt] -> [b, 1, nt]."""
+    -> Conv1d(F->1, 1)(x*mask) * mask.  Dropout is the identity at inference.  tokens [b, nt] (pad -1), mask [b, nt] -> [b, 1, nt].
+    ``g_cond`` [b, gin, 1] or [b, gin, nt]: the optional speaker conditioning of a net built with gin_channels != 0."""
     F_ = torch.nn.functional
     g = lambda n: W[prefix + n].float()
     ids = tokens.long() + (1 if add_one else 0)
     x = g("text_embed.weight")[ids].transpose(1, 2)  # [b, C, nt]
+    if g_cond is not None:  # speaker conditioning (:25-26, :33-35): x + Conv1d(gin -> C, 1)(g), g [b, gin, 1 | nt]
+        x = x + F_.conv1d(g_cond.float(), g("cond.weight"), g("cond.bias"))
     m = mask.float().unsqueeze(1)  # [b, 1, nt]
     k = g("conv_1.weight").shape[-1]
     for i in ("1", "2"):

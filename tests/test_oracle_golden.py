@@ -221,6 +221,17 @@ def test_mel_and_istft_consistency():
     assert torch.allclose(mine, ref, atol=1e-5)
 
 
+def test_duration_predictor_speaker_conditioning_matches_reference_fixture():
+    """the g path of oracle/cpu_ref.duration_predictor vs the reference DurationPredictor(gin_channels = 12) (tests/golden/duration_predictor_g.npz)."""
+    g = load_golden("duration_predictor_g")
+    W = {k[2:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("w.")}
+    tokens, mask = torch.from_numpy(g["tokens"]), torch.from_numpy(g["mask"])
+    g1, gt = torch.from_numpy(g["g1"]), torch.from_numpy(g["gt"])
+    assert rel_l2(cpu_ref.duration_predictor(W, tokens, mask, g_cond=g1), torch.from_numpy(g["out_g1"])) < 2e-6
+    assert rel_l2(cpu_ref.duration_predictor(W, tokens, mask, g_cond=gt), torch.from_numpy(g["out_gt"])) < 2e-6
+    assert rel_l2(cpu_ref.duration_predictor(W, tokens.clamp(min=0), mask, add_one=False, g_cond=g1), torch.from_numpy(g["out_phoneme_g1"])) < 2e-6
+
+
 def test_duration_predictor_matches_reference_fixture():
     """oracle/cpu_ref.duration_predictor vs the reference DurationPredictor's own outputs (tests/golden/duration_predictor.npz)."""
     g = load_golden("duration_predictor")
