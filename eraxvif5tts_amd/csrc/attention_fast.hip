@@ -779,20 +779,58 @@ bool attention_fast_supported(int precision, int N, int H) { return precision ==
 
 int launch_attention_pipe(int waves, int B, int N, int H, const void* qkv, int ldq, const uint8_t* mask, void* out, int ldo, hipStream_t stream, int bstride);  // attention_pipe.hip
 
-int launch_attention_fast(int B, int N, int H, const void* qkv, int ldq, const uint8_t* mask, void* out, int ldo, hipStream_t stream, int bstride) {
-    if ((ldq & 7) || (ldo & 7)) return f5_fail(F5_EINVAL, "attention_fast: ldq and ldo must be multiples of 8");
-    // 256 queries per workgroup need at least one workgroup per CU to pay; below that (single-utterance serving) the 128-query
-    // workgroups of the pipelined kernel fill the chip better (B = 1: 17 vs 23 us)
+int launch_attention_pipe_segs(bool masked, int nbr, const AttnSegs& segs, int maxN, int H, const void* qkv, int ldq, void* out, int ldo, hipStream_t stream,
+                               int bstride);  // attention_pipe.hip
+
+static int cu_count_cached() {
     static int cus = 0;
     if (cus == 0) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
-    const bool masked = mask != nullptr || (N % 64) != 0;
-    bool wide = g_attn_variant == 2 || g_attn_variant == 6 || (g_attn_variant == 0 && (long)B * H * cdiv(N, 256) >= cus);
+    return cus;
+}
+// which of the two tuned kernels launch_attention_fast gives a (B, N, H) problem
+static bool picks_wide(int B, int N, int H, bool masked, int ldq, int bstride) {
+    // 256 queries per workgroup need at least one workgroup per CU to pay; below that (single-utterance serving) the 128-query
+    // workgroups of the pipelined kernel fill the chip better (B = 1: 17 vs 23 us)
+    bool wide = g_attn_variant == 2 || g_attn_variant == 6 || (g_attn_variant == 0 && (long)B * H * cdiv(N, 256) >= cu_count_cached());
     if (masked && N > 64 * 128) wide = false;  // the wide kernel's table of key validity bits holds 128 tiles
     if ((size_t)N * (size_t)ldq * 2u >= (1ull << 32)) wide = false;  // its per-lane key offsets are 32-bit
     if ((size_t)bstride * (size_t)ldq * 2u >= (1ull << 32)) wide = false;
+    return wide;
+}
+
+int launch_attention_ragged(int precision, int attn_kernel_opt, const AttnSegs& segs, int H, const void* qkv, int ldq, void* out, int ldo, hipStream_t stream,
+                            int bstride) {
+    const size_t es = precision == F5_PREC_BF16 ? 2 : 4;
+    AttnSegs grp[2];  // [0] utterances with n % 64 == 0 (unmasked build), [1] the others -- as each one's own launch would pick
+    int maxn[2] = {0, 0};
+    for (int u = 0; u < segs.cnt; ++u) {
+        const int nu = segs.n[u];
+        const int kind = (attn_kernel_opt != 0 && attention_fast_supported(precision, nu, H)) ? 1 : 0;
+        const bool masked = (nu % 64) != 0;
+        if (kind == 1 && (ldq & 7) == 0 && (ldo & 7) == 0 && !picks_wide(segs.nbr, nu, H, masked, ldq, bstride)) {
+            AttnSegs& g = grp[masked ? 1 : 0];
+            g.nbr = segs.nbr;
+            g.off[g.cnt] = segs.off[u];
+            g.n[g.cnt++] = nu;
+            maxn[masked ? 1 : 0] = std::max(maxn[masked ? 1 : 0], nu);
+        } else {  // its own launch: the wide kernel, or the reference kernel
+            F5_TRY(launch_attention(precision, kind, segs.nbr, nu, H, (const char*)qkv + (size_t)segs.off[u] * ldq * es, ldq, nullptr,
+                                    (char*)out + (size_t)segs.off[u] * ldo * es, ldo, stream, bstride));
+        }
+    }
+    for (int k = 0; k < 2; ++k)
+        if (grp[k].cnt > 0) F5_TRY(launch_attention_pipe_segs(k == 1, segs.nbr, grp[k], maxn[k], H, qkv, ldq, out, ldo, stream, bstride));
+    return 0;
+}
+
+int launch_attention_fast(int B, int N, int H, const void* qkv, int ldq, const uint8_t* mask, void* out, int ldo, hipStream_t stream, int bstride) {
+    if ((ldq & 7) || (ldo & 7)) return f5_fail(F5_EINVAL, "attention_fast: ldq and ldo must be multiples of 8");
+    const int cus = cu_count_cached();
+    const bool masked = mask != nullptr || (N % 64) != 0;
+    const bool wide = picks_wide(B, N, H, masked, ldq, bstride);
     if (!wide) return launch_attention_pipe(4, B, N, H, qkv, ldq, mask, out, ldo, stream, bstride);
     const float c = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
     // persistent grid (two workgroups per CU walking items, K/V ring and Q prefetch running on across items): unmasked whole 256-query blocks,

@@ -64,10 +64,14 @@ __device__ __forceinline__ float sum_halves(float v) {
 //   1 no exp2 (P = the scaled score), 2 no PV MFMAs, 4 no QK^T MFMAs, 8 no K/V tile refresh (no global loads, LDS writes or barriers),
 //   16 no row-sum adds, 32 no row max, 64 no LDS fragment reads in the loop, 128 / 256 no K / no V fragment reads, 512 fragments read
 //   and waited for but the MFMAs take register operands
-template <bool MASKED, int WAVES, int ABL = 0, int WPE = 2>
+// SEG (ragged sampler): the launch covers several utterances of different lengths that sit at row offsets inside a longer concatenation;
+// batch index = utterance * nbr + branch, N and the row offset come from `segs`, query blocks past an utterance's end leave at once.  Every
+// other block computes exactly what it computes in a launch over its utterance alone (same N, same rows).
+template <bool MASKED, int WAVES, int ABL = 0, int WPE = 2, bool SEG = false>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void attn_pipe_kernel(const bf16_t* __restrict__ qkv, int ldq, int inner,
                                                                                  const uint8_t* __restrict__ mask, bf16_t* __restrict__ out,
-                                                                                 int ldo, int N, int bs /* rows between batch items */, float c /* scale * log2(e) */) {
+                                                                                 int ldo, int N, int bs /* rows between batch items */, float c /* scale * log2(e) */,
+                                                                                 AttnSegs segs) {
     constexpr int KT = 64;                // keys per tile
     constexpr int TB = KT * 128;          // 64 keys x 64 dims x 2 B
     constexpr int NTH = WAVES * 64, CH = 512 / NTH, QW = 32 * WAVES;
@@ -84,7 +88,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE,
     }
     const int b = bh / gridDim.y, head = bh - b * gridDim.y, q0 = qb * QW + wave * 32;
     const int r = lane & 31, h = lane >> 5;
-    const bf16_t* base = qkv + (size_t)b * bs * ldq + head * 64;
+    size_t row0 = (size_t)b * bs;
+    if constexpr (SEG) {
+        const int u = b / segs.nbr, br = b - u * segs.nbr;
+        N = segs.n[u];
+        if (qb * QW >= N) return;  // (the whole workgroup: nothing has been issued yet)
+        row0 = (size_t)br * bs + segs.off[u];
+    }
+    const bf16_t* base = qkv + row0 * ldq + head * 64;
     const bf16_t* kbase = base + inner;
     const bf16_t* vbase = base + 2 * inner;
 
@@ -413,7 +424,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE,
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     const int qrow = q0 + r;
     if (qrow < N) {
-        bf16_t* op = out + ((size_t)b * bs + qrow) * ldo + head * 64 + 4 * h;
+        bf16_t* op = out + (row0 + qrow) * ldo + head * 64 + 4 * h;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -434,9 +445,24 @@ int launch_attention_pipe(int waves, int B, int N, int H, const void* qkv, int l
     const bool masked = mask != nullptr || (N % 64) != 0;
     const dim3 grid(cdiv(N, 128), H, B);
     if (masked)
-        hipLaunchKernelGGL((attn_pipe_kernel<true, 4>), grid, dim3(256), 0, stream, (const bf16_t*)qkv, ldq, H * 64, mask, (bf16_t*)out, ldo, N, bstride, c);
+        hipLaunchKernelGGL((attn_pipe_kernel<true, 4>), grid, dim3(256), 0, stream, (const bf16_t*)qkv, ldq, H * 64, mask, (bf16_t*)out, ldo, N, bstride, c, AttnSegs{});
     else
-        hipLaunchKernelGGL((attn_pipe_kernel<false, 4>), grid, dim3(256), 0, stream, (const bf16_t*)qkv, ldq, H * 64, mask, (bf16_t*)out, ldo, N, bstride, c);
+        hipLaunchKernelGGL((attn_pipe_kernel<false, 4>), grid, dim3(256), 0, stream, (const bf16_t*)qkv, ldq, H * 64, mask, (bf16_t*)out, ldo, N, bstride, c, AttnSegs{});
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+// several utterances (all with N % 64 == 0, or all without) of one ragged batch in ONE launch: grid.z = utterance x branch
+int launch_attention_pipe_segs(bool masked, int nbr, const AttnSegs& segs, int maxN, int H, const void* qkv, int ldq, void* out, int ldo, hipStream_t stream,
+                               int bstride) {
+    const float c = 0.125f * 1.4426950408889634f;
+    const dim3 grid(cdiv(maxN, 128), H, nbr * segs.cnt);
+    if (masked)
+        hipLaunchKernelGGL((attn_pipe_kernel<true, 4, 0, 2, true>), grid, dim3(256), 0, stream, (const bf16_t*)qkv, ldq, H * 64, (const uint8_t*)nullptr, (bf16_t*)out, ldo, maxN,
+                           bstride, c, segs);
+    else
+        hipLaunchKernelGGL((attn_pipe_kernel<false, 4, 0, 2, true>), grid, dim3(256), 0, stream, (const bf16_t*)qkv, ldq, H * 64, (const uint8_t*)nullptr, (bf16_t*)out, ldo, maxN,
+                           bstride, c, segs);
     F5_LAUNCH_CHECK();
     return 0;
 }

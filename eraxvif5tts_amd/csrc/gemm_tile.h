@@ -15,10 +15,10 @@ template <int N, int I = 0, typename F> __device__ __forceinline__ void static_f
 // exp2/rcp forms of the activations for the bf16 epilogues (the output rounding to bf16 dominates their ~1 ulp error):
 //   gelu_tanh(x) = 0.5 x (1 + tanh(u)) = x * sigmoid(2u),  u = sqrt(2/pi) (x + 0.044715 x^3)
 //   mish(x)      = x tanh(softplus(x)) = x * n / (n + 2),  n = e^x (e^x + 2)
-// The three epilogue expressions that contain a multiply feeding an add are written with EXPLICIT fused multiply-adds (epi_* below): the
-// whole-tile ("lean") and the ragged-tile ("generic") epilogues of gemm_fast.hip then round identically whatever the compiler's contraction
-// heuristics make of their different surroundings -- a token row's value must not depend on whether its 256-row tile is whole
-// (f5_sample_ragged: every utterance equals its own batch-1 call bit for bit, where it sits in other tiles).
+// The three epilogue expressions that contain a multiply feeding an add exist ONCE, with explicit fused multiply-adds (epi_* below; the library
+// is built with -ffp-contract=off, so nothing else fuses): until round 3 the whole-tile ("lean") epilogue of gemm_fast.hip used fused forms and
+// the ragged-tile ("generic") one separate multiplies and adds, i.e. a token row's value depended on whether its 256-row tile was whole.  It
+// must not: f5_sample_ragged promises every utterance the bits of its own batch-1 call, where its rows sit in other tiles.
 __device__ __forceinline__ float fast_gelu_tanh(float x) {
     const float a = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
     const float u2 = x * __builtin_fmaf(x * x, a * 0.044715f, a);

@@ -9,6 +9,15 @@
 int launch_attention(int precision, int kernel_kind, int B, int N, int H, const void* qkv, int ldq, const uint8_t* mask, void* out,
                      int ldo, hipStream_t stream, int bstride = 0);
 bool attention_fast_supported(int precision, int N, int H);
+// utterances of a ragged batch (f5_sample_ragged): row offset and length of each inside one half of the concatenation
+struct AttnSegs {
+    int nbr = 1, cnt = 0;  // batch items per utterance (CFG branches), utterances in this table
+    int off[12] = {0}, n[12] = {0};
+};
+// attention over `cnt` utterances of different lengths, each the computation of launch_attention(precision, kind_u, nbr, n[u], ...) on its
+// own rows (bstride rows between the branches): utterances whose own launch would take the pipelined kernel share launches, the rest get theirs
+int launch_attention_ragged(int precision, int attn_kernel_opt, const AttnSegs& segs, int H, const void* qkv, int ldq, void* out, int ldo, hipStream_t stream,
+                            int bstride);
 
 // ---- elementwise.hip
 // out[r][c] = LN(x[r][:])[c] * (add_one + mul[b(r)][c]) + add[b(r)][c]; b(r) = r / rows_per_batch; eps 1e-6

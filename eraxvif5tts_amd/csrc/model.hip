@@ -1013,12 +1013,16 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         } else {
             F5_TRY(timed(p, F5_SITE_QKV, st, [&] { return run_gemm(p, g, GEMM_DENSE, EPI_ROPE_T, st); }));
         }
-        if (rg) {  // one launch per utterance: exactly the launch a batch-1 sample() of that utterance makes, on its rows of both halves
-            for (size_t u = 0; u < rg->n.size(); ++u) {
-                const int nu = rg->n[u];
-                const int kind = (p->attn_kernel != 0 && attention_fast_supported(P, nu, c.heads)) ? 1 : 0;
-                F5_TRY(launch_attention(P, kind, nb, nu, c.heads, (const char*)p->qkv + (size_t)rg->off[u] * 3 * inner * aes, 3 * inner, nullptr,
-                                        (char*)p->cT + (size_t)rg->off[u] * inner * aes, inner, st, N));
+        if (rg) {  // every utterance gets the computation of the launch its own batch-1 sample() makes, on its rows of both halves; the ones
+                   // that launch would give to the pipelined kernel share launches (grid.z = utterance x branch, 12 utterances per table)
+            for (size_t u0 = 0; u0 < rg->n.size(); u0 += 12) {
+                AttnSegs sg;
+                sg.nbr = nb;
+                for (size_t u = u0; u < rg->n.size() && u < u0 + 12; ++u) {
+                    sg.off[sg.cnt] = rg->off[u];
+                    sg.n[sg.cnt++] = rg->n[u];
+                }
+                F5_TRY(launch_attention_ragged(P, p->attn_kernel, sg, c.heads, p->qkv, 3 * inner, p->cT, inner, st, N));
             }
         } else {
             int kind = 0;

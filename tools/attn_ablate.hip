@@ -37,10 +37,10 @@ template <int WAVES, int ABL, int WPE = 2, int PADLDS = 0> static float run(int 
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     for (int i = 0; i < 2; ++i)
-        hipLaunchKernelGGL((attn_pipe_kernel<false, WAVES, ABL, WPE>), grid, dim3(WAVES * 64), PADLDS, 0, qkv, 3 * H * 64, H * 64, (const uint8_t*)nullptr, out, H * 64, N, N, c);
+        hipLaunchKernelGGL((attn_pipe_kernel<false, WAVES, ABL, WPE>), grid, dim3(WAVES * 64), PADLDS, 0, qkv, 3 * H * 64, H * 64, (const uint8_t*)nullptr, out, H * 64, N, N, c, AttnSegs{});
     CK(hipEventRecord(e0, 0));
     for (int i = 0; i < iters; ++i)
-        hipLaunchKernelGGL((attn_pipe_kernel<false, WAVES, ABL, WPE>), grid, dim3(WAVES * 64), PADLDS, 0, qkv, 3 * H * 64, H * 64, (const uint8_t*)nullptr, out, H * 64, N, N, c);
+        hipLaunchKernelGGL((attn_pipe_kernel<false, WAVES, ABL, WPE>), grid, dim3(WAVES * 64), PADLDS, 0, qkv, 3 * H * 64, H * 64, (const uint8_t*)nullptr, out, H * 64, N, N, c, AttnSegs{});
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms = 0.f;
