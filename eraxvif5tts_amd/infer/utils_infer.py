@@ -201,28 +201,36 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
     if len(ref_text[-1].encode("utf-8")) == 1:
         ref_text = ref_text + " "
 
-    def process_batch(gen_text):
+    ref_audio_len = audio.shape[-1] // hop_length
+
+    def plan_batch(gen_text):  # host side of one text batch: tokens and the frame budget (reference :455-470)
         local_speed = 0.3 if len(gen_text.encode("utf-8")) < 10 else speed
         final_text_list = convert_char_to_pinyin([ref_text + gen_text])
-        ref_audio_len = audio.shape[-1] // hop_length
         if fix_duration is not None:
             duration = int(fix_duration * target_sample_rate / hop_length)
         else:
             ref_text_len, gen_text_len = len(ref_text.encode("utf-8")), len(gen_text.encode("utf-8"))
             duration = ref_audio_len + int(ref_audio_len / ref_text_len * gen_text_len / local_speed)
+        return final_text_list, duration
+
+    def finish_batch(generated):  # mel -> wave (reference :481-497)
+        generated = generated.to(torch.float32)[:, ref_audio_len:, :].permute(0, 2, 1)
+        generated_wave = vocoder.decode(generated)
+        if rms < target_rms:
+            generated_wave = generated_wave * rms / target_rms
+        return generated_wave.squeeze().cpu().numpy(), generated[0].cpu().numpy()
+
+    def process_batch(gen_text):
+        final_text_list, duration = plan_batch(gen_text)
         with torch.inference_mode():
             generated, _ = model_obj.sample(cond=audio, text=final_text_list, duration=duration, steps=nfe_step, cfg_strength=cfg_strength,
                                             sway_sampling_coef=sway_sampling_coef, return_trajectory=False)
-            generated = generated.to(torch.float32)[:, ref_audio_len:, :].permute(0, 2, 1)
-            generated_wave = vocoder.decode(generated)
-            if rms < target_rms:
-                generated_wave = generated_wave * rms / target_rms
-            generated_wave = generated_wave.squeeze().cpu().numpy()
+            generated_wave, mel = finish_batch(generated)
             if streaming:
                 for j in range(0, len(generated_wave), chunk_size):
                     yield generated_wave[j: j + chunk_size], target_sample_rate
             else:
-                yield generated_wave, generated[0].cpu().numpy()
+                yield generated_wave, mel
 
     batches = progress.tqdm(gen_text_batches) if progress is not None else gen_text_batches
     if streaming:
@@ -231,6 +239,27 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
                 yield chunk
         return
     generated_waves, spectrograms = [], []
+    # Several text batches, each long enough for the tuned kernels: ONE ragged batch per group (F5TTSWrapper.generate does the same; every
+    # utterance keeps the arithmetic -- and the noise draw order -- of its own batch-1 sample() call, so the audio is bit-identical).
+    transformer = getattr(model_obj, "transformer", None)
+    jobs = [plan_batch(t) for t in gen_text_batches]
+    group_max = int(os.environ.get("F5HIP_RAGGED_CHUNKS", "8"))
+    if (group_max >= 2 and len(jobs) >= 2 and hasattr(model_obj, "sample_ragged") and hasattr(transformer, "native_sample_ragged")
+            and getattr(transformer, "BACKBONE", None) == 0 and min(d for _, d in jobs) >= 256 and max(d for _, d in jobs) <= 4096):
+        with torch.inference_mode():
+            i = 0
+            while i < len(jobs):
+                group, rows = [], 0
+                while i < len(jobs) and len(group) < group_max and (not group or rows + jobs[i][1] <= 16384):
+                    group.append(jobs[i])
+                    rows += jobs[i][1]
+                    i += 1
+                for generated in model_obj.sample_ragged(audio, [j[0][0] for j in group], [j[1] for j in group], steps=nfe_step,
+                                                         cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef):
+                    wave, mel = finish_batch(generated)
+                    generated_waves.append(wave)
+                    spectrograms.append(mel)
+        batches = []
     for gen_text in batches:  # the reference's thread pool resolves to serial generators on the caller thread
         wave, mel = next(process_batch(gen_text))
         generated_waves.append(wave)

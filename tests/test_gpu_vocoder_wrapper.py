@@ -197,7 +197,7 @@ def test_wrapper_end_to_end(tmp_path):
         tts.calculate_duration_with_predictor(torch.tensor([[5, 6, 7]], device="cuda"), torch.tensor([3], device="cuda"))
 
 
-def test_infer_process_batch_process_and_safetensors_checkpoint(tmp_path):
+def test_infer_process_batch_process_and_safetensors_checkpoint(tmp_path, monkeypatch):
     """utils_infer.load_model on a .safetensors EMA checkpoint (reference utils_infer.py:184-226, f5tts_wrapper.py:224-229),
     infer_process / infer_batch_process (reference utils_infer.py:366-563): chunk bookkeeping, the streaming generator, and the
     ORIGINAL-rms rule of infer_batch_process (:440-442,491-492), all over the HIP sampler + HIP vocoder."""
@@ -248,6 +248,12 @@ def test_infer_process_batch_process_and_safetensors_checkpoint(tmp_path):
     torch.manual_seed(6)
     whole, _, _ = next(U.infer_batch_process((a, rate), ref_text, batches, model, vocoder, nfe_step=2, device="cuda", cross_fade_duration=0))
     assert np.array_equal(np.concatenate([c[0] for c in chunks]), whole)
+    # (the non-streaming call sampled its two batches as ONE ragged batch -- both have >= 256 frames; the serial order gives the same samples)
+    monkeypatch.setenv("F5HIP_RAGGED_CHUNKS", "0")
+    torch.manual_seed(6)
+    serial, _, _ = next(U.infer_batch_process((a, rate), ref_text, batches, model, vocoder, nfe_step=2, device="cuda", cross_fade_duration=0))
+    monkeypatch.delenv("F5HIP_RAGGED_CHUNKS")
+    assert np.array_equal(serial, whole)
 
     # original-rms rule: a prompt quieter than the target is boosted for conditioning and the output scaled back by rms / target
     rms = float(torch.sqrt(torch.mean(torch.square(a))))
