@@ -227,6 +227,83 @@ __global__ __launch_bounds__(256) void layernorm1024_h_kernel(const _Float16* x,
 #pragma unroll
     for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(pfv[r]));  // keeps the prefetch loads alive
 }
+// The read-only pass of the in-place-residual mode (YMODE 0) with ONE modulation row for every token (the sampler: one time per evaluation):
+// a wave normalises RPW consecutive rows and keeps the 2 x 1024 modulation values in registers across them -- per row the kernel above issues
+// 2 loads of the stream and 8 of the modulation rows (L1 hits, but 4/5 of its load instructions).  Same arithmetic per row, bit for bit.
+template <int RPW>
+__global__ __launch_bounds__(256) void layernorm1024_h_rows_kernel(const _Float16* __restrict__ x, int ldx, int rows, const float* __restrict__ mul,
+                                                                   const float* __restrict__ add, float add_one, bf16_t* __restrict__ out, int ldo,
+                                                                   PrefetchSet pf, unsigned* sat, int sat_tag) {
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    unsigned pfv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        pfv[r] = 0u;
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            const unsigned line = (unsigned)(row0 + k) * 64u + lane;
+            if (pf.p[r] && line * 128u < pf.n[r]) pfv[r] ^= *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(pf.p[r]) + (size_t)line * 128);
+        }
+    }
+    if (row0 >= rows) return;
+    f16x8 xr[RPW][2];
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+        const int row = row0 + k < rows ? row0 + k : rows - 1;  // (rows past the end are computed on the last row and not stored)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) xr[k][i] = *reinterpret_cast<const f16x8*>(x + (size_t)row * ldx + (lane + i * 64) * 8);
+    }
+    f32x4 m4[2][2], a4[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = (lane + i * 64) * 8;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            m4[i][hh] = *reinterpret_cast<const f32x4*>(mul + c + 4 * hh);
+            a4[i][hh] = *reinterpret_cast<const f32x4*>(add + c + 4 * hh);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+        const int row = row0 + k;
+        float v[2][8];
+        float s = 0.f, amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[i][e] = (float)xr[k][i][e];
+                amax = fmaxf(amax, fabsf(v[i][e]));
+            }
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            s += (v[i][4] + v[i][5]) + (v[i][6] + v[i][7]);
+        }
+        res_range_guard(sat, amax, s, sat_tag, row < rows ? row : rows - 1);
+        const float mean = wave_sum(s) / 1024.0f;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[i][e] - mean;
+                q += d * d;
+            }
+        const float rstd = rsqrtf(wave_sum(q) / 1024.0f + 1e-6f);
+        if (row < rows) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((v[i][e] - mean) * rstd * (add_one + m4[i][e >> 2][e & 3]) + a4[i][e >> 2][e & 3]);
+                *reinterpret_cast<bf16x8*>(out + (size_t)row * ldo + (lane + i * 64) * 8) = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(pfv[r]));  // keeps the prefetch loads alive
+}
+int g_ln_rows = 2;  // tuning knob ("ln_rows"): rows per wave of the read-only LayerNorm pass (1 = the one-row kernel; same-box A/B at C2, pair of passes: 96.4 us -> 90.8 with 2, 93.3 with 4)
 int g_ln_wide = 1;  // tuning knob ("ln_wide"): 16-byte form of the LayerNorm pass at its production shape
 
 template <typename TO, int MAXV, typename XI = float, typename XO = float>
@@ -278,7 +355,14 @@ int launch_layernorm_res(int precision_out, const void* xin, int xin_f16, void* 
 #define F5_LN_W(M)                                                                                                                              \
     hipLaunchKernelGGL((layernorm1024_h_kernel<M>), grid, block, 0, stream, (const _Float16*)xin, (_Float16*)xout, ldx, rows, (const bf16_t*)y, ldy, \
                        (const bf16_t*)y2, mul, add, mod_bstride, rows_per_batch, one, (bf16_t*)out, ldo, pfs, sat, sat_tag)
-        if (ymode == 0) F5_LN_W(0);
+        if (ymode == 0 && mod_bstride == 0 && xin == xout && (g_ln_rows == 2 || g_ln_rows == 4) && rows >= 16384) {
+            if (g_ln_rows == 4)
+                hipLaunchKernelGGL((layernorm1024_h_rows_kernel<4>), dim3(cdiv(rows, 16)), block, 0, stream, (const _Float16*)xin, ldx, rows, mul, add, one,
+                                   (bf16_t*)out, ldo, pfs, sat, sat_tag);
+            else
+                hipLaunchKernelGGL((layernorm1024_h_rows_kernel<2>), dim3(cdiv(rows, 8)), block, 0, stream, (const _Float16*)xin, ldx, rows, mul, add, one,
+                                   (bf16_t*)out, ldo, pfs, sat, sat_tag);
+        } else if (ymode == 0) F5_LN_W(0);
         else if (ymode == 1) F5_LN_W(1);
         else if (ymode == 2) F5_LN_W(2);
         else F5_LN_W(3);

@@ -149,6 +149,22 @@ def test_dit_constructor_switches_match_reference(tag):
     assert rel_l2(traj, z[f"{tag}.sample_traj"]) < 2e-5 and rel_l2(out, z[f"{tag}.sample_out"]) < 2e-5
 
 
+def test_true_size_sampler_matches_reference():
+    """CFM.sample of the reference over its true-size F5TTS_Base DiT (B = 2, unequal durations -> key mask, NFE 3, CFG 2, sway -1, seeded noise)
+    vs the oracle's sample() on the same weights (regenerated from the seed) and the same initial noise (trajectory row 0)."""
+    z = load_golden("base_sample")
+    cfg = dict(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, text_mask_padding=False, conv_layers=4, pe_attn_head=1)
+    W = cpu_ref.random_dit_weights(cfg, int(z["vocab"]), seed=int(z["seed"]))
+    g = lambda k: torch.from_numpy(z[k])
+    out, traj = cpu_ref.sample(W, cfg, g("cond"), g("text"), g("duration"), lens=g("lens"), steps=3, cfg_strength=2.0, sway_sampling_coef=-1.0,
+                               y0=g("traj")[0])
+    assert rel_l2(traj, z["traj"]) < 5e-5 and rel_l2(out, z["out"]) < 5e-5
+    # the reference's own seeded noise: manual_seed(11) then randn(duration, 100) per sample (cfm.py:178-183)
+    out2, _ = cpu_ref.sample(W, cfg, g("cond"), g("text"), g("duration"), lens=g("lens"), steps=1, cfg_strength=0.0, seed=11)
+    torch.manual_seed(11)
+    assert torch.equal(g("traj")[0, 0], torch.randn(96, 100))
+
+
 def _mmdit_case(z, tag):
     import ast
     arch = ast.literal_eval(str(z[f"{tag}.arch"]))
