@@ -303,6 +303,7 @@ __global__ __launch_bounds__(256) void layernorm1024_h_rows_kernel(const _Float1
 #pragma unroll
     for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(pfv[r]));  // keeps the prefetch loads alive
 }
+int g_ln_rows_min = 16384;  // tuning knob ("ln_rows_min"): smallest launch (token rows) that takes the multi-row kernel
 int g_ln_rows = 2;  // tuning knob ("ln_rows"): rows per wave of the read-only LayerNorm pass (1 = the one-row kernel; same-box A/B at C2, pair of passes: 96.4 us -> 90.8 with 2, 93.3 with 4)
 int g_ln_wide = 1;  // tuning knob ("ln_wide"): 16-byte form of the LayerNorm pass at its production shape
 
@@ -355,7 +356,7 @@ int launch_layernorm_res(int precision_out, const void* xin, int xin_f16, void* 
 #define F5_LN_W(M)                                                                                                                              \
     hipLaunchKernelGGL((layernorm1024_h_kernel<M>), grid, block, 0, stream, (const _Float16*)xin, (_Float16*)xout, ldx, rows, (const bf16_t*)y, ldy, \
                        (const bf16_t*)y2, mul, add, mod_bstride, rows_per_batch, one, (bf16_t*)out, ldo, pfs, sat, sat_tag)
-        if (ymode == 0 && mod_bstride == 0 && xin == xout && (g_ln_rows == 2 || g_ln_rows == 4) && rows >= 16384) {
+        if (ymode == 0 && mod_bstride == 0 && xin == xout && (g_ln_rows == 2 || g_ln_rows == 4) && rows >= g_ln_rows_min) {
             if (g_ln_rows == 4)
                 hipLaunchKernelGGL((layernorm1024_h_rows_kernel<4>), dim3(cdiv(rows, 16)), block, 0, stream, (const _Float16*)xin, ldx, rows, mul, add, one,
                                    (bf16_t*)out, ldo, pfs, sat, sat_tag);
