@@ -30,3 +30,21 @@ for (B, N, nfe, reps) in [(32, 1024, 8, 40), (3, 777, 8, 30), (1, 1024, 8, 30), 
     print(f"B={B} N={N} NFE={nfe}: {reps} runs, {bad} differ from the first, finite={bool(torch.isfinite(ref).all())}, {time.perf_counter() - t0:.1f} s", flush=True)
     assert bad == 0
 print("soak ok")
+# the ragged batch (utterance table in the pipelined attention kernel's grid, zero gap rows, per-row RoPE table): repeated calls must agree bit for bit
+g = torch.Generator().manual_seed(9)
+cond1 = (torch.randn(1, 300, 100, generator=g) * 2 - 3).cuda()
+durs = [760, 1010, 900, 1180, 333, 512]
+texts = [torch.randint(0, bench.VOCAB, (1, d // 7), generator=g).cuda() for d in durs]
+y0s = [torch.randn(1, d, 100, generator=g).cuda() for d in durs]
+ref, bad = None, 0
+t0 = time.perf_counter()
+for it in range(20):
+    outs = cfm.sample_ragged(cond1, texts, durs, y0s=y0s, steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0)
+    cat = torch.cat([o[0] for o in outs])
+    if ref is None:
+        ref = cat.clone()
+    elif not torch.equal(cat, ref):
+        bad += 1
+torch.cuda.synchronize()
+print(f"ragged {durs} NFE=4: 20 runs, {bad} differ from the first, finite={bool(torch.isfinite(ref).all())}, {time.perf_counter() - t0:.1f} s", flush=True)
+assert bad == 0
