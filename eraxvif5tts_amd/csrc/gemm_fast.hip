@@ -28,12 +28,15 @@ typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 
 template <int BN, int WM, int MODE, int EPI, int VAR, int NS>
 __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int tiles_n, int nblocks) {
-    constexpr int BM = 256, BK = 32, WN = 64, NSTAGE = NS;
+    constexpr int BK = 32, WN = 64, NSTAGE = NS;
     constexpr int WAVES_N = BN / WN;
+    constexpr int BM = (8 / WAVES_N) * WM;  // 256 token rows (WM = 128 / 64 / 32 for BN = 256 / 128 / 64); 128 for the small-launch tiles (BN = 128, WM = 32; BN = 64, WM = 16)
+    constexpr int APW = BM / 128;           // activation DMA pieces (16 rows x 64 B) per wave per K-step
+    static_assert(BM == 256 || BM == 128, "token-tile heights");
     constexpr int MI = WM / 16, NI = WN / 16;
     constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
     constexpr int WJ = BN >= 256 ? 2 : 1;  // weight DMA pieces (16 rows x 64 B) per wave per K-step (BN = 64: waves 4-7 duplicate 0-3)
-    constexpr int PPW = 2 + WJ;            // DMA pieces per wave per K-step (vmcnt bookkeeping)
+    constexpr int PPW = APW + WJ;          // DMA pieces per wave per K-step (vmcnt bookkeeping)
     static_assert((BM / WM) * WAVES_N == 8, "8 waves");
     __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE];
 
@@ -84,17 +87,17 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
     // ---- DMA source bookkeeping: 2 A pieces + WJ W pieces per wave per K-step, each piece = 16 rows x 64 B
     const int prow = lane >> 2, pchunk = lane & 3;
     const int plc = pchunk ^ ((0 - (prow >> 2)) & 3);  // logical 16-byte chunk stored at this physical slot (piece rows are 16-aligned)
-    const bf16_t* a_src[2];
-    int a_pos[2];
-    bool a_ok[2];
+    const bf16_t* a_src[APW];
+    int a_pos[APW];
+    bool a_ok[APW];
     const bf16_t* w_src[WJ];
     int w_piece[WJ];
 #pragma unroll
     for (int j = 0; j < WJ; ++j) w_piece[j] = (wave * WJ + j) % (BN / 16);
     auto setup_src = [&](int sm0, int sn0) {  // DMA sources of tile (sm0, sn0)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            int gm = sm0 + (wave * 2 + j) * 16 + prow;
+        for (int j = 0; j < APW; ++j) {
+            int gm = sm0 + (wave * APW + j) * 16 + prow;
             a_ok[j] = gm < p.M;
             if (gm >= p.M) gm = p.M - 1;
             a_pos[j] = 0;
@@ -125,20 +128,22 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
     auto issue_piece = [&](int slot, int kt, int piece) {
         char* sbase = smem + slot * STAGE;
         if constexpr (MODE == GEMM_DENSE) {
-            if (piece < 2)
-                dma16(a_src[piece] + (size_t)kt * BK, sbase + (wave * 2 + piece) * 1024);
+            if (piece < APW)
+                dma16(a_src[piece < APW ? piece : 0] + (size_t)kt * BK, sbase + (wave * APW + piece) * 1024);
             else
-                dma16(w_src[piece - 2] + (size_t)kt * BK, sbase + A_BYTES + w_piece[piece - 2] * 1024);
+                dma16(w_src[piece >= APW ? piece - APW : 0] + (size_t)kt * BK, sbase + A_BYTES + w_piece[piece >= APW ? piece - APW : 0] * 1024);
         } else {
             const int tap = kt / cslices, sl = kt - tap * cslices;
             const int ch0 = win0 + sl * BK;
-            if (piece < 2) {
-                const int sp = a_pos[piece] + tap - 15;  // Conv1d(padding=15): zero outside [0, L) of this utterance
-                const bool ok = a_ok[piece] && sp >= 0 && sp < L && (ch0 + plc * 8) < p.N;
-                const void* src = ok ? (const void*)(a_src[piece] + (ptrdiff_t)(tap - 15) * p.lda + ch0) : (const void*)g_zero_page;
-                dma16(src, sbase + (wave * 2 + piece) * 1024);
+            if (piece < APW) {
+                const int ap = piece < APW ? piece : 0;
+                const int sp = a_pos[ap] + tap - 15;  // Conv1d(padding=15): zero outside [0, L) of this utterance
+                const bool ok = a_ok[ap] && sp >= 0 && sp < L && (ch0 + plc * 8) < p.N;
+                const void* src = ok ? (const void*)(a_src[ap] + (ptrdiff_t)(tap - 15) * p.lda + ch0) : (const void*)g_zero_page;
+                dma16(src, sbase + (wave * APW + piece) * 1024);
             } else {
-                dma16(w_src[piece - 2] + (size_t)tap * p.N * p.conv_win + sl * BK, sbase + A_BYTES + w_piece[piece - 2] * 1024);
+                const int wp = piece >= APW ? piece - APW : 0;
+                dma16(w_src[wp] + (size_t)tap * p.N * p.conv_win + sl * BK, sbase + A_BYTES + w_piece[wp] * 1024);
             }
         }
     };
@@ -227,7 +232,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
     // Loads (row mask, RoPE table, addend / residual) are issued in groups BEFORE any store of the group: vmcnt retires
     // in order, so a load issued behind a store would also wait for that store's round trip.
     auto generic_epilogue = [&]() {
-    constexpr int JG = (EPI == EPI_RESID || EPI == EPI_GATE_T) ? 2 : (MI >= 4 ? 4 : MI);  // token tiles per load group (register budget)
+    constexpr int JG0 = (EPI == EPI_RESID || EPI == EPI_GATE_T) ? 2 : (MI >= 4 ? 4 : MI);  // token tiles per load group (register budget)
+    constexpr int JG = JG0 < MI ? JG0 : MI;
     static_for<MI / JG>([&](auto gc) {
         constexpr int j0 = decltype(gc)::value * JG;
         int mrow[JG];
@@ -750,6 +756,7 @@ static int persist_grid() {
     }
     return cus;
 }
+int g_gemm_bm128 = 1;  // tuning knob ("gemm_bm128"): 128-row token tiles when the 256-row ones leave CUs without a workgroup (single-utterance launches)
 int g_gemm_lean = 1;   // tuning knob ("gemm_lean"): 1 = lean epilogue on whole tiles, 0 = generic epilogue everywhere
 
 template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmParams& p0, hipStream_t stream) {
@@ -758,7 +765,8 @@ template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmPa
     p.tile_group = g_gemm_group > 0 ? g_gemm_group : (cdiv(p.N, BN) == 8 ? 16 : 8);
     p.lean_epi = g_gemm_lean;
     p.clk = g_gemm_clk_buf;
-    const int tiles_m = cdiv(p.M, 256), tiles_n = cdiv(p.N, BN);
+    constexpr int BMv = (8 / (BN / 64)) * WM;  // token rows of a tile (see the kernel)
+    const int tiles_m = cdiv(p.M, BMv), tiles_n = cdiv(p.N, BN);
     const int nblocks = tiles_m * tiles_n;
     dim3 grid(nblocks), block(512);
     // persistent grid (one workgroup per CU walking tiles, next tile's first K-steps prefetched under the epilogue, bias folded into the
@@ -815,11 +823,20 @@ int launch_gemm_fast(const GemmParams& p, int mode, int epi, hipStream_t stream)
     // tile width by occupancy: the 256-wide tile is the efficient one, narrower tiles keep the 256 CUs busy when the token count
     // is small (single-utterance serving: M = 2 x frames)
     const int tiles_m = cdiv(p.M, 256);
-    int bn = 256;
+    int bn = 256, bm = 256;
     if (p.N % 256 != 0 || tiles_m * (p.N / 256) < 160) bn = 128;
     if (bn == 128 && p.N % 64 == 0 && tiles_m * cdiv(p.N, 128) < 160) bn = 64;
+    // still fewer workgroups than CUs want (single-utterance serving: M = 2 x frames, N = 1024): 128-row token tiles double the count.
+    // Every accumulator sums K in the same order whatever the tile, so the result bits do not change (knob "gemm_bm128": 2 forces them).
+    if (g_gemm_bm128 == 2 || (g_gemm_bm128 == 1 && bn == 64 && tiles_m * cdiv(p.N, 64) < 160)) {
+        bm = 128;
+        bn = (g_gemm_bm128 == 2 && p.N % 128 == 0 && cdiv(p.M, 128) * (p.N / 128) >= 320) ? 128 : 64;
+        if (p.N % 64 != 0) bn = 128;
+    }
 #define F5_FAST_CASE(E)                                                                   \
     case E:                                                                               \
+        if (bm == 128 && bn == 128) return launch_fast<128, 32, GEMM_DENSE, E>(p, stream); \
+        if (bm == 128) return launch_fast<64, 16, GEMM_DENSE, E>(p, stream);              \
         if (bn == 256) return launch_fast<256, 128, GEMM_DENSE, E>(p, stream);            \
         if (bn == 128) return launch_fast<128, 64, GEMM_DENSE, E>(p, stream);             \
         return launch_fast<64, 32, GEMM_DENSE, E>(p, stream);

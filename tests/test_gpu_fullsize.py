@@ -410,7 +410,7 @@ def test_concurrent_chunks_equal_serial_chunks_and_are_faster():
         times.setdefault(name, []).append(time.perf_counter() - t0)
     ts, tc = min(times["serial"]), min(times["concurrent"])
     print(f"4 chunks ({durs} frames, NFE 8): serial {ts * 1e3:.1f} ms, concurrent on 4 streams {tc * 1e3:.1f} ms -> {ts / tc:.2f}x")
-    assert tc < ts / 1.3
+    assert tc < ts / 1.15  # (1.38 x before the 128-row GEMM tiles made the serial calls themselves 11 % faster; 1.28 x since)
 
 
 def test_ragged_chunks_equal_serial_chunks_and_are_faster():
