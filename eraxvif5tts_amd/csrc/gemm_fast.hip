@@ -826,12 +826,20 @@ int launch_gemm_fast(const GemmParams& p, int mode, int epi, hipStream_t stream)
     int bn = 256, bm = 256;
     if (p.N % 256 != 0 || tiles_m * (p.N / 256) < 160) bn = 128;
     if (bn == 128 && p.N % 64 == 0 && tiles_m * cdiv(p.N, 128) < 160) bn = 64;
-    // still fewer workgroups than CUs want (single-utterance serving: M = 2 x frames, N = 1024): 128-row token tiles double the count.
-    // Every accumulator sums K in the same order whatever the tile, so the result bits do not change (knob "gemm_bm128": 2 forces them).
-    if (g_gemm_bm128 == 2 || (g_gemm_bm128 == 1 && bn == 64 && tiles_m * cdiv(p.N, 64) < 160)) {
+    // Small launches (single-utterance serving: M = 2 x frames): 128-row token tiles.  (a) the 256 x 64 tiling still leaves CUs without a
+    // workgroup: 128 x 64 doubles the count (M = 2048: out-projection 20.8 -> 15.8 us, FF2 33.6 -> 24.6 us); (b) 256 x 64 fills the CUs but
+    // 128 x 128 does too with a fifth fewer operand rows per K-step (M = 4096: out-projection 22.2 -> 20.7 us, FF2 35.4 -> 32.5 us; M = 2048
+    // FF1 20.4 -> 19.4 us).  Every accumulator sums K in the same order whatever the tile, so the result bits do not change.
+    // Knob "gemm_bm128": 0 never, 1 these two rules, 2 128-row tiles everywhere (tests).
+    if (g_gemm_bm128 == 2) {
         bm = 128;
-        bn = (g_gemm_bm128 == 2 && p.N % 128 == 0 && cdiv(p.M, 128) * (p.N / 128) >= 320) ? 128 : 64;
+        bn = (p.N % 128 == 0 && cdiv(p.M, 128) * (p.N / 128) >= 320) ? 128 : 64;
         if (p.N % 64 != 0) bn = 128;
+    } else if (g_gemm_bm128 == 1 && bn == 64 && tiles_m * cdiv(p.N, 64) < 160) {
+        bm = 128;
+    } else if (g_gemm_bm128 == 1 && bn == 64 && p.N % 128 == 0 && cdiv(p.M, 128) * (p.N / 128) >= 160) {
+        bm = 128;
+        bn = 128;
     }
 #define F5_FAST_CASE(E)                                                                   \
     case E:                                                                               \
