@@ -756,6 +756,7 @@ static int persist_grid() {
     }
     return cus;
 }
+int g_gemm_tile = 0;   // diagnostic knob ("gemm_tile"): bm * 1000 + bn forces the tile of every tuned-GEMM launch that supports it (0 = by shape)
 int g_gemm_bm128 = 1;  // tuning knob ("gemm_bm128"): 128-row token tiles when the 256-row ones leave CUs without a workgroup (single-utterance launches)
 int g_gemm_lean = 1;   // tuning knob ("gemm_lean"): 1 = lean epilogue on whole tiles, 0 = generic epilogue everywhere
 
@@ -824,7 +825,9 @@ int launch_gemm_fast(const GemmParams& p, int mode, int epi, hipStream_t stream)
     // is small (single-utterance serving: M = 2 x frames)
     const int tiles_m = cdiv(p.M, 256);
     int bn = 256, bm = 256;
-    if (p.N % 256 != 0 || tiles_m * (p.N / 256) < 160) bn = 128;
+    // (a 128-wide tiling of more workgroups than CUs would run in two rounds: the 256-wide one, with at least 129 tiles then, wins --
+    //  M = 3072 QKV: 144 tiles of 256 x 256 33.3 us against 288 of 256 x 128 42.0 us)
+    if (p.N % 256 != 0 || (tiles_m * (p.N / 256) < 160 && tiles_m * cdiv(p.N, 128) <= persist_grid())) bn = 128;
     if (bn == 128 && p.N % 64 == 0 && tiles_m * cdiv(p.N, 128) < 160) bn = 64;
     // Small launches (single-utterance serving: M = 2 x frames): 128-row token tiles.  (a) the 256 x 64 tiling still leaves CUs without a
     // workgroup: 128 x 64 doubles the count (M = 2048: out-projection 20.8 -> 15.8 us, FF2 33.6 -> 24.6 us); (b) 256 x 64 fills the CUs but
@@ -840,6 +843,13 @@ int launch_gemm_fast(const GemmParams& p, int mode, int epi, hipStream_t stream)
     } else if (g_gemm_bm128 == 1 && bn == 64 && p.N % 128 == 0 && cdiv(p.M, 128) * (p.N / 128) >= 160) {
         bm = 128;
         bn = 128;
+    }
+    if (g_gemm_tile > 0) {
+        const int fbm = g_gemm_tile / 1000, fbn = g_gemm_tile % 1000;
+        if ((fbm == 256 || fbm == 128) && (fbn == 256 || fbn == 128 || fbn == 64) && !(fbm == 128 && fbn == 256) && p.N % fbn == 0) {
+            bm = fbm;
+            bn = fbn;
+        }
     }
 #define F5_FAST_CASE(E)                                                                   \
     case E:                                                                               \
