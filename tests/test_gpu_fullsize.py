@@ -456,3 +456,28 @@ def test_ragged_chunks_equal_serial_chunks_and_are_faster():
     ts, tr = min(times["serial"]), min(times["ragged"])
     print(f"4 chunks ({durs} frames, NFE 8): serial {ts * 1e3:.1f} ms, one ragged batch {tr * 1e3:.1f} ms -> {ts / tr:.2f}x")
     assert tr < ts / 1.5
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_c1_config_matches_oracle(prec):
+    """BASELINE.json configs[0] -- the reference's own CPU-runnable case: F5TTS_Base random-init, ONE utterance, seq_len 256, NFE 8, CFG
+    strength 1 -- through CFM.sample on the GPU (eager and hipGraph replay) against the CPU oracle on the same weights and noise (a 16-forward
+    run of the true-size network on the host cores: seconds)."""
+    import bench
+    from eraxvif5tts_amd.model import CFM, DiT
+    from oracle import cpu_ref
+    torch.manual_seed(4321)
+    model = bench.synth_weights(DiT(**bench.BASE_ARCH, text_num_embeds=bench.VOCAB, mel_dim=100, precision=prec), seed=0)
+    cfm = CFM(transformer=model, mel_spec_kwargs={"mel_spec_type": "vocos"}).cuda()
+    W = {k: v.detach().cpu().float() for k, v in model.state_dict().items()}
+    cond, text, lens, dur = bench.synth_batch(1, 256, "cuda", seed=3)
+    g = torch.Generator().manual_seed(5)
+    y0 = torch.randn(1, 256, 100, generator=g)
+    ref, _ = cpu_ref.sample(W, bench.BASE_ARCH, cond.cpu(), text.cpu(), dur.cpu(), lens=lens.cpu(), steps=8, cfg_strength=1.0, sway_sampling_coef=-1.0,
+                            y0=y0, return_trajectory=False)
+    tol = {"fp32": 2e-4, "bf16": 2e-2}[prec]
+    for use_graph in (False, True, True):
+        out, _ = cfm.sample(cond=cond, text=text, duration=dur, lens=lens, steps=8, cfg_strength=1.0, sway_sampling_coef=-1.0, y0=y0.cuda(),
+                            return_trajectory=False, use_graph=use_graph)
+        n_ref = int(lens[0])
+        assert rel_l2(out.cpu()[:, n_ref:], ref[:, n_ref:]) < tol, (prec, use_graph)
