@@ -987,9 +987,11 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         // Tile quantisation at small batches: the fused projection has 12 feature tiles per token tile; when the q|k part alone (8 tiles
         // per token tile) fills the CUs a whole number of times but q|k|v does not (M = 8192, 4 utterances x 1024 frames x CFG: 256 + 128
         // tiles on 256 CUs, the second round half empty), v is projected by its own launch on 256 x 128 tiles: 70 -> 62 us per block.
-        const int tiles_m = rows / 256, ncu = f5_cu_count();
-        const bool split_v = P == F5_PREC_BF16 && p->gemm_kernel != 0 && rows % 256 == 0 && inner % 256 == 0 && (tiles_m * (2 * inner / 256)) % ncu == 0 &&
-                             (tiles_m * (3 * inner / 256)) % ncu != 0 && tiles_m * (inner / 256) < ncu;
+        // (round 3, late: any token count whose q|k tiles fit one round while q|k|v would need a second -- ragged batches, odd batch sizes:
+        //  M = 6144: 288 tiles of 256 x 256 = two rounds, 60 us; 192 + 192 narrower ones: 53 us.  Same sums either way.)
+        const int tiles_m = (rows + 255) / 256, ncu = f5_cu_count();
+        const bool split_v = P == F5_PREC_BF16 && p->gemm_kernel != 0 && inner % 256 == 0 && tiles_m * (2 * inner / 256) <= ncu &&
+                             tiles_m * (3 * inner / 256) > ncu && tiles_m * (2 * inner / 256) >= 160;
         if (c.qk_norm) {  // q, k stored as projected; RMSNorm per head, then RoPE, in place (modules.py:463-475)
             g.rope = nullptr;
             g.rope_inner = g.rope_heads = 0;
