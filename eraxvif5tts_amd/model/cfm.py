@@ -127,8 +127,9 @@ class CFM(nn.Module):
         """``sample()`` for several texts over ONE prompt, each with its own duration, in one set of kernel launches without padding the
         utterances to a common length (libf5hip ``f5_sample_ragged``).  Equivalent to ``[sample(cond, [t], d)[0] for t, d in zip(texts,
         durations)]`` -- the reference's batch-1 arithmetic per utterance (cfm.py:82-208 with batch = 1: no key mask), noise drawn in the
-        same order -- and returns that list ([1, N_i, mel] each).  cond: mel [1, nc, mel] or raw wave [1, nw]; texts: list of str / list of
-        token lists; durations: list of ints."""
+        same order -- and returns that list ([1, N_i, mel] each).  cond: mel [1, nc, mel] or raw wave [1, nw] (one prompt for every text), or
+        [B, nc, mel] with ``lens`` (a prompt per utterance, zero-padded to a common nc as for ``sample()``); texts: list of str / list of token
+        lists / id tensor; durations: list of ints."""
         self.eval()
         native = getattr(self.transformer, "native_sample_ragged", None)
         if native is None:
@@ -136,9 +137,9 @@ class CFM(nn.Module):
         if cond.ndim == 2:  # raw wave
             cond = self.mel_spec(cond).permute(0, 2, 1)
         cond = cond.to(next(self.parameters()).dtype)
-        assert cond.shape[0] == 1 and cond.shape[-1] == self.num_channels
-        cond_seq_len, device = cond.shape[1], cond.device
         nutt = len(texts)
+        assert cond.shape[0] in (1, nutt) and cond.shape[-1] == self.num_channels
+        cond_seq_len, device = cond.shape[1], cond.device
         if not exists(lens):
             lens = torch.full((nutt,), cond_seq_len, device=device, dtype=torch.long)
         if isinstance(texts, torch.Tensor):  # token ids [B, nt], -1 padded
@@ -154,7 +155,7 @@ class CFM(nn.Module):
         frames = [int(d) for d in duration]
         conds, noises = [], []
         for i, n in enumerate(frames):
-            conds.append(F.pad(cond[0], (0, 0, 0, n - cond_seq_len), value=0.0))
+            conds.append(F.pad(cond[i if cond.shape[0] > 1 else 0], (0, 0, 0, n - cond_seq_len), value=0.0))
             if y0s is not None:
                 noises.append(y0s[i].reshape(n, self.num_channels).to(device=device, dtype=cond.dtype))
             else:
