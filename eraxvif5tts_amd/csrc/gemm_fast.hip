@@ -762,8 +762,10 @@ int g_gemm_lean = 1;   // tuning knob ("gemm_lean"): 1 = lean epilogue on whole 
 
 template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmParams& p0, hipStream_t stream) {
     GemmParams p = p0;
-    // L2 patch height: 8 token tiles per XCD patch; 16 for the 8-feature-tile (N = 2048) projection (FF1 985 -> 1 020 TFLOP/s)
-    p.tile_group = g_gemm_group > 0 ? g_gemm_group : (cdiv(p.N, BN) == 8 ? 16 : 8);
+    // L2 patch height: 8 token tiles per XCD patch.  (Until late in round 3 the 8-feature-tile projection -- FF1, N = 2048 -- took 16: +3 % on
+    // that launch in isolation, but in situ the FF2 launch behind it reads FF1's output and runs 277 -> 267 us when FF1 wrote it in patches of
+    // 8 like its own: same-box A/B x 3 at C2, 30 408 -> 30 575 mel-frames/s.)
+    p.tile_group = g_gemm_group > 0 ? g_gemm_group : 8;
     p.lean_epi = g_gemm_lean;
     p.clk = g_gemm_clk_buf;
     constexpr int BMv = (8 / (BN / 64)) * WM;  // token rows of a tile (see the kernel)
