@@ -756,6 +756,7 @@ static int persist_grid() {
     }
     return cus;
 }
+int g_gemm_group_sites = 0;  // diagnostic knob ("gemm_group_sites"): patch height per block call site, two decimal digits each: qkv|out|ff1|ff2
 int g_gemm_tile = 0;   // diagnostic knob ("gemm_tile"): bm * 1000 + bn forces the tile of every tuned-GEMM launch that supports it (0 = by shape)
 int g_gemm_bm128 = 1;  // tuning knob ("gemm_bm128"): 128-row token tiles when the 256-row ones leave CUs without a workgroup (single-utterance launches)
 int g_gemm_lean = 1;   // tuning knob ("gemm_lean"): 1 = lean epilogue on whole tiles, 0 = generic epilogue everywhere
@@ -766,6 +767,14 @@ template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmPa
     // that launch in isolation, but in situ the FF2 launch behind it reads FF1's output and runs 277 -> 267 us when FF1 wrote it in patches of
     // 8 like its own: same-box A/B x 3 at C2, 30 408 -> 30 575 mel-frames/s.)
     p.tile_group = g_gemm_group > 0 ? g_gemm_group : 8;
+    if (g_gemm_group_sites > 0) {  // diagnostic: per call site, decimal digits pairs qkv|out|ff1|ff2 (e.g. 8160804)
+        const int site = p.N == 3 * p.K ? 0 : (p.N == p.K ? 1 : (p.N == 2 * p.K ? 2 : (p.K == 2 * p.N ? 3 : -1)));
+        static const int div[4] = {1000000, 10000, 100, 1};
+        if (site >= 0) {
+            const int v = (g_gemm_group_sites / div[site]) % 100;
+            if (v > 0) p.tile_group = v;
+        }
+    }
     p.lean_epi = g_gemm_lean;
     p.clk = g_gemm_clk_buf;
     constexpr int BMv = (8 / (BN / 64)) * WM;  // token rows of a tile (see the kernel)
