@@ -49,6 +49,7 @@ struct GemmParams {
     // CONV31: channels per group (dim/16) and the padded input-channel window one 64-channel output tile reads
     int conv_cg, conv_win;
     int tile_group;  // tuned kernel: token tiles per L2 patch (set by the launcher)
+    int tile_reverse;  // tuned kernel: walk the tiles in the opposite order (producer / consumer cache experiments)
     int lean_epi;    // tuned kernel: whole tiles take the lean epilogue (set by the launcher; 0 = always the generic one)
     unsigned long long* clk;  // diagnostic (f5_debug_gemm_clock): [workgroups][4] = (s_memtime, s_memrealtime) at workgroup start and end, or null
 };

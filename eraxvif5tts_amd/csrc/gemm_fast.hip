@@ -65,7 +65,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
     // its L2 has to hold per K-step
     auto tile_mn = [&](int bid, int& tm0, int& tn0) {
         const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7;
-        const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        if (p.tile_reverse) swz = nblocks - 1 - swz;
         const int gm = p.tile_group > 0 ? p.tile_group : 1;
         const int tiles_m_all = nblocks / tiles_n;
         const int grp = swz / (gm * tiles_n);
@@ -756,6 +757,11 @@ static int persist_grid() {
     }
     return cus;
 }
+// tuning knob ("gemm_reverse_sites"): bit mask of block call sites (bit 0 qkv, 1 out, 2 ff1, 3 ff2) that walk their tiles backwards.  Default 8:
+// FF2 reads FF1's 256 MiB output -- more than the 256 MB Infinity Cache holds -- so walking it in FF1's order finds the oldest lines evicted
+// all the way, the opposite order meets the newest half while it is still cached: FF2 272.5 -> 267.3 us in situ, C2 30 185 -> 30 328
+// mel-frames/s (same-box A/B; reversing FF1 instead does the same, both together nothing, the other sites nothing).  Same values either way.
+int g_gemm_reverse_sites = 8;
 int g_gemm_group_sites = 0;  // diagnostic knob ("gemm_group_sites"): patch height per block call site, two decimal digits each: qkv|out|ff1|ff2
 int g_gemm_tile = 0;   // diagnostic knob ("gemm_tile"): bm * 1000 + bn forces the tile of every tuned-GEMM launch that supports it (0 = by shape)
 int g_gemm_bm128 = 1;  // tuning knob ("gemm_bm128"): 128-row token tiles when the 256-row ones leave CUs without a workgroup (single-utterance launches)
@@ -767,6 +773,10 @@ template <int BN, int WM, int MODE, int EPI> static int launch_fast(const GemmPa
     // that launch in isolation, but in situ the FF2 launch behind it reads FF1's output and runs 277 -> 267 us when FF1 wrote it in patches of
     // 8 like its own: same-box A/B x 3 at C2, 30 408 -> 30 575 mel-frames/s.)
     p.tile_group = g_gemm_group > 0 ? g_gemm_group : 8;
+    if (g_gemm_reverse_sites > 0) {  // bit 0 qkv, 1 out-projection, 2 FF1, 3 FF2 walk their tiles backwards
+        const int site = p.N == 3 * p.K ? 0 : (p.N == p.K ? 1 : (p.N == 2 * p.K ? 2 : (p.K == 2 * p.N ? 3 : -1)));
+        if (site >= 0 && ((g_gemm_reverse_sites >> site) & 1)) p.tile_reverse = 1;
+    }
     if (g_gemm_group_sites > 0) {  // diagnostic: per call site, decimal digits pairs qkv|out|ff1|ff2 (e.g. 8160804)
         const int site = p.N == 3 * p.K ? 0 : (p.N == p.K ? 1 : (p.N == 2 * p.K ? 2 : (p.K == 2 * p.N ? 3 : -1)));
         static const int div[4] = {1000000, 10000, 100, 1};
