@@ -15,17 +15,24 @@
 //     ds_read_b128 at any tap shift.
 // Weights are the tap-major image the model already builds for the generic path: [31][dim][64] (GemmParams::conv_win == 64).
 #include "gemm_tile.h"
+#include "runtime.h"
 
 __device__ __attribute__((aligned(256))) unsigned char g_conv_zero_page[256];  // zero-initialised: Conv1d zero padding / rows outside the utterance
 
 namespace {
 
-constexpr int TAPS = 31, HALO = 15, TOK = 256, ROWS = TOK + 2 * HALO;  // 286 halo rows
-constexpr int A_PIECES = (ROWS + 7) / 8;                                // 36 DMA pieces of 8 rows x 128 B
-constexpr int A_BYTES = A_PIECES * 1024, W_BYTES = 64 * 128;
+constexpr int TAPS = 31, HALO = 15, W_BYTES = 64 * 128;
 constexpr int WSLOTS = 4, WAHEAD = WSLOTS - 1;  // weight slices in LDS / taps fetched ahead (4 slots: 68 KiB -> 2 workgroups per CU)
 
+// TOK = 256 tokens per workgroup (64 per wave); TOK = 128 (32 per wave) for launches that would otherwise leave CUs without a workgroup
+// (single utterance: 4 token tiles x 16 groups x 2 branches = 128 workgroups of 256 tokens).  Same sums per output either way.
+template <int TOK>
 __global__ __launch_bounds__(256, 2) void conv31_kernel(GemmParams p, int tiles_per_seq) {
+    constexpr int ROWS = TOK + 2 * HALO;            // 286 / 158 halo rows
+    constexpr int A_PIECES = (ROWS + 7) / 8;        // 36 / 20 DMA pieces of 8 rows x 128 B
+    constexpr int A_BYTES = A_PIECES * 1024;
+    constexpr int TW = TOK / 4, TJ = TW / 16;       // tokens per wave, 16-token tiles per wave
+    static_assert(A_PIECES % 4 == 0, "pieces divide over the 4 waves");
     __shared__ __attribute__((aligned(16))) char smem[A_BYTES + WSLOTS * W_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x, grp = blockIdx.y, b = blockIdx.z;
@@ -59,11 +66,11 @@ __global__ __launch_bounds__(256, 2) void conv31_kernel(GemmParams p, int tiles_
     const int fr = lane & 15, fq = lane >> 4;
     const int wrow_sw = (fr >> 1) & 7;  // weight rows 16 * i + fr: (row >> 1) & 7 does not depend on i
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][TJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int tap = 0; tap < TAPS; ++tap) {
         // my pieces of the halo tile (tap 0) and of this tap's weights have landed: only the slices fetched behind them (2 pieces
@@ -80,19 +87,19 @@ __global__ __launch_bounds__(256, 2) void conv31_kernel(GemmParams p, int tiles_
         const char* wb = smem + A_BYTES + (tap % WSLOTS) * W_BYTES + fr * 128;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 wf[4], af[4];
+            bf16x8 wf[4], af[TJ];
             const int wc = ((ks * 4 + fq) ^ wrow_sw) * 16;
 #pragma unroll
             for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wb + i * 2048 + wc);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = wave * 64 + j * 16 + fr + tap;
+            for (int j = 0; j < TJ; ++j) {
+                const int row = wave * TW + j * 16 + fr + tap;
                 af[j] = *reinterpret_cast<const bf16x8*>((const char*)smem + row * 128 + (((ks * 4 + fq) ^ ((row >> 1) & 7)) * 16));
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
         }
     }
 
@@ -103,9 +110,9 @@ __global__ __launch_bounds__(256, 2) void conv31_kernel(GemmParams p, int tiles_
     const int ncol = grp * 64 + 16 * (fq & 1) + 8 * (fq >> 1);
     bf16_t* out = reinterpret_cast<bf16_t*>(p.out_t) + (size_t)b * L * p.ldo + ncol;
     const int act = p.act;
-    static_for<4>([&](auto jc) {
+    static_for<TJ>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        const int tok = n0 + wave * 64 + j * 16 + fr;
+        const int tok = n0 + wave * TW + j * 16 + fr;
         static_for<2>([&](auto hc) {
             constexpr int i0 = decltype(hc)::value * 2;
             f32x4 v0 = acc[i0][j] + bias4[i0], v1 = acc[i0 + 1][j] + bias4[i0 + 1];
@@ -135,10 +142,19 @@ bool conv31_supported(const GemmParams& p, int precision, int epi) {
     return epi == EPI_STORE_T;
 }
 
+int g_conv31_tok = 0;  // tuning knob ("conv31_tok"): tokens per workgroup, 0 = by grid size, 128 or 256 forced
 int launch_conv31(const GemmParams& p, hipStream_t stream) {
-    const int L = p.rows_per_batch, nb = p.M / L, tiles = cdiv(L, TOK);
+    const int L = p.rows_per_batch, nb = p.M / L;
     if (nb > 65535) return f5_fail(F5_EINVAL, "conv31: batch %d too large for one launch", nb);
-    hipLaunchKernelGGL(conv31_kernel, dim3(tiles, p.N / 64, nb), dim3(256), 0, stream, p, tiles);
+    const bool small = g_conv31_tok == 128 || (g_conv31_tok == 0 && (long)cdiv(L, 256) * (p.N / 64) * nb < 2L * f5_cu_count());
+    if (small) {
+        const int tiles = cdiv(L, 128);
+        hipLaunchKernelGGL(conv31_kernel<128>, dim3(tiles, p.N / 64, nb), dim3(256), 0, stream, p, tiles);
+        F5_LAUNCH_CHECK();
+        return 0;
+    }
+    const int tiles = cdiv(L, 256);
+    hipLaunchKernelGGL(conv31_kernel<256>, dim3(tiles, p.N / 64, nb), dim3(256), 0, stream, p, tiles);
     F5_LAUNCH_CHECK();
     return 0;
 }

@@ -360,6 +360,7 @@ extern "C" int f5_bench_mfma_rate(int random_operands, float* tflops, f5_stream_
 }
 
 extern int g_sync_evals, g_attn_persist, g_attn_stagger, g_resid_rmw;
+extern int g_conv31_tok;
 extern int g_gemm_bm128, g_gemm_tile, g_gemm_group_sites, g_gemm_reverse_sites;
 extern int g_gemm_variant, g_gemm_group, g_gemm_persist_grid, g_gemm_persist, g_gemm_lean, g_ln_defer, g_ln_wide, g_ln_rows, g_ln_rows_min, g_w_prefetch, g_res_f16, g_conv31, g_attn_variant, g_vocos_fft;
 int g_tuning_epoch = 0;
@@ -410,6 +411,10 @@ extern "C" int f5_tuning_set(const char* key, int value) {
     }
     if (strcmp(key, "gemm_group_sites") == 0) {
         g_gemm_group_sites = value;
+        return 0;
+    }
+    if (strcmp(key, "conv31_tok") == 0) {
+        g_conv31_tok = value;
         return 0;
     }
     if (strcmp(key, "gemm_tile") == 0) {
