@@ -269,7 +269,8 @@ def insitu_kernels(model, cfm, batch, B, N, nfe, args):
 
 def extra_workloads(args, dev, model, cfm):
     """The other single-GPU configurations of BASELINE.json, measured after the C2 line so that the driver's default run records them too:
-    C4 (long form, 8 x 4096: 2 timed sample() calls + the in-situ kernel table) and C5 (Vocos.decode on the generated part of C2)."""
+    C4 (long form, 8 x 4096: 2 timed sample() calls + the in-situ kernel table), the 4 x 1024 shard shape of the 8-GPU run and the
+    single-utterance shape (5 timed sample() calls each), and C5 (Vocos.decode on the generated part of C2)."""
     import torch
     out = {}
     B, N, nfe = WORKLOADS["C4"][0], WORKLOADS["C4"][1], args.nfe
@@ -296,6 +297,27 @@ def extra_workloads(args, dev, model, cfm):
                  "attention_frac": attn["frac"] if attn else None, "attention_ms": attn["ms"] if attn else None,
                  "loop_mfma_frac": round(flops / el / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "kernels": kernels}
     del batch, cond, text, lens, duration, o
+    torch.cuda.empty_cache()
+    # the two small shapes the other claims rest on: the per-GPU shard of the 8-GPU strong-scaling run (4 x 1024) and one utterance (1 x 1024:
+    # what F5TTSWrapper.generate() pays per text chunk when it cannot batch them)
+    for key, b in (("shard_4x1024", 4), ("single_utterance", 1)):
+        cond, text, lens, duration = synth_batch(b, 1024, dev, seed=0)
+        kw = dict(cond=cond, text=text, duration=duration, lens=lens, steps=nfe, cfg_strength=args.cfg, sway_sampling_coef=-1.0, seed=0,
+                  return_trajectory=False, use_graph=not args.no_graph)
+        cfm.sample(**kw)
+        cfm.sample(**kw)  # (the second call of a shape is the one that captures the graph)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 5
+        for _ in range(n):
+            o, _ = cfm.sample(**kw)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / n
+        assert torch.isfinite(o).all()
+        out[key] = {"value": round(b * 1024 / el, 2), "unit": "mel-frames/s", "ms_per_step": round(el * 1e3, 3),
+                    "rtf": round(el / (b * (1024 - 1024 // 3) * 256 / 24000.0), 6),
+                    "config": f"{b} utterance(s) x seq_len 1024 (N_ref=341), NFE={nfe} CFG={args.cfg:g} sway=-1, bf16, hipGraph"}
+        del cond, text, lens, duration, o
     torch.cuda.empty_cache()
     v = bench_vocos(args, dev, T=683, B=32, steps=20, warmup=3)
     out["C5"] = {"value": v["value"], "unit": v["unit"], "ms_per_step": v["ms_per_step"], "rtf": v["rtf"], "config": v["config"]["workload"],
