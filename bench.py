@@ -319,6 +319,37 @@ def extra_workloads(args, dev, model, cfm):
                     "config": f"{b} utterance(s) x seq_len 1024 (N_ref=341), NFE={nfe} CFG={args.cfg:g} sway=-1, bf16, hipGraph"}
         del cond, text, lens, duration, o
     torch.cuda.empty_cache()
+    # the text chunks of one F5TTSWrapper.generate() call (reference infer/f5tts_wrapper.py:476-533 samples them one after the other): four
+    # utterances of different lengths over one prompt, serial batch-1 calls against ONE ragged batch (f5_sample_ragged; bit-identical mels)
+    g = torch.Generator().manual_seed(31)
+    cond1 = (torch.randn(1, 300, 100, generator=g) * 2 - 3).clamp(math.log(1e-5), 3.0).to(dev)
+    durs = [760, 1010, 900, 1180]
+    texts = [torch.randint(0, VOCAB, (1, d // 7), generator=g).to(dev) for d in durs]
+    y0s = [torch.randn(1, d, 100, generator=g).to(dev) for d in durs]
+    skw = dict(steps=nfe, cfg_strength=args.cfg, sway_sampling_coef=-1.0)
+
+    def serial():
+        return [cfm.sample(cond=cond1, text=t, duration=d, y0=y, return_trajectory=False, use_graph=False, **skw)[0] for t, d, y in zip(texts, durs, y0s)]
+
+    def ragged():
+        return cfm.sample_ragged(cond1, texts, durs, y0s=y0s, **skw)
+
+    ref, got = serial(), ragged()
+    torch.cuda.synchronize()
+    same = all(torch.equal(a, b) for a, b in zip(got, ref))
+    times = {}
+    for name, fn in (("serial", serial), ("ragged", ragged), ("serial", serial), ("ragged", ragged)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        times.setdefault(name, []).append(time.perf_counter() - t0)
+    ts, tr = min(times["serial"]), min(times["ragged"])
+    out["generate_4_chunks"] = {"value": round(sum(durs) / tr, 2), "unit": "mel-frames/s", "ms_per_step": round(tr * 1e3, 3),
+                                "serial_ms": round(ts * 1e3, 3), "speedup_vs_serial": round(ts / tr, 3), "bit_identical_to_serial": bool(same),
+                                "config": f"4 utterances of {durs} frames over one 300-frame prompt, NFE={nfe} CFG={args.cfg:g} sway=-1, bf16, eager launches"}
+    del ref, got, cond1, texts, y0s
+    torch.cuda.empty_cache()
     v = bench_vocos(args, dev, T=683, B=32, steps=20, warmup=3)
     out["C5"] = {"value": v["value"], "unit": v["unit"], "ms_per_step": v["ms_per_step"], "rtf": v["rtf"], "config": v["config"]["workload"],
                  "head_gbs": v["roofline"]["achieved"], "head_frac": v["roofline"]["frac"],
