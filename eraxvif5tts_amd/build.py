@@ -57,15 +57,32 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
         return LIB
     hipcc = _hipcc()
+    # an object is reused when its own source, every header and its flags are unchanged (per-object stamp next to it)
+    hdr = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)) + ["../../include/f5hip.h"]:
+        if f.endswith(".h"):
+            with open(os.path.join(CSRC, f), "rb") as fh:
+                hdr.update(f.encode())
+                hdr.update(fh.read())
 
     def compile_one(src):
         obj = os.path.join(BUILD, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+        extra = EXTRA_FLAGS.get(src, [])
+        h = hdr.copy()
+        with open(os.path.join(CSRC, src), "rb") as fh:
+            h.update(fh.read())
+        h.update(" ".join(FLAGS + extra).encode())
+        ostamp = obj + ".digest"
+        if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read() == h.hexdigest():
+            return obj
+        cmd = [hipcc, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
+        with open(ostamp, "w") as fh:
+            fh.write(h.hexdigest())
         return obj
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 2)) as ex:

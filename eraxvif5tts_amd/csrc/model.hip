@@ -92,6 +92,7 @@ struct PendingSample {
     int use_graph = 0;
     float* out = nullptr;
     float* trajectory = nullptr;
+    hipStream_t stream = nullptr;  // the stream the deferred call was enqueued on
 };
 
 struct f5_plan_s {
@@ -147,28 +148,48 @@ struct f5_plan_s {
     std::vector<GraphEntry> graphs;
     hipStream_t cap_stream = nullptr;  // capture happens on a private stream (the caller's may be the legacy null stream)
     // in-situ timing of the block kernels: HIP event pairs around every launch of an eager sample() (f5_plan_timing_*)
+    // The pairs live in a BOUNDED ring (F5_EV_RING pairs, created once per plan and reused): when it is full the older half is folded into
+    // site_ms -- the host waits for the last event of that half, while the younger half's launches are still queued, so the device never idles.
     bool timing = false;
-    std::vector<hipEvent_t> ev;
-    std::vector<int> ev_site;  // call site of pair i (F5_SITE_*)
-    size_t ev_used = 0;
-    bool ev_overflow = false;  // a launch found the event pool full: the means would cover the early launches only
+    std::vector<hipEvent_t> ev;   // 2 * F5_EV_RING events: pair i = ev[2i], ev[2i+1]
+    std::vector<int> ev_site;     // call site of pair i (F5_SITE_*)
+    size_t ev_head = 0, ev_live = 0;  // oldest unfolded pair, number of unfolded pairs
     double site_ms[F5_SITE_COUNT] = {0};
     int site_n[F5_SITE_COUNT] = {0};
 };
+static const size_t F5_EV_RING = 512;
+
+// folds the `count` oldest recorded pairs into the per-site sums (blocks until the last of them has completed)
+static void timing_fold(f5_plan_s* p, size_t count) {
+    count = std::min(count, p->ev_live);
+    if (!count) return;
+    (void)hipEventSynchronize(p->ev[2 * ((p->ev_head + count - 1) % F5_EV_RING) + 1]);
+    for (size_t k = 0; k < count; ++k) {
+        const size_t i = (p->ev_head + k) % F5_EV_RING;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p->ev[2 * i], p->ev[2 * i + 1]) == hipSuccess) {
+            p->site_ms[p->ev_site[i]] += ms;
+            ++p->site_n[p->ev_site[i]];
+        }
+    }
+    p->ev_head = (p->ev_head + count) % F5_EV_RING;
+    p->ev_live -= count;
+}
 
 // runs `launch` (a kernel launcher returning a status) between an event pair tagged with `site` while timing is on
 template <typename F> static int timed(f5_plan_s* p, int site, hipStream_t st, F&& launch) {
-    if (p->timing && p->ev_used + 2 <= p->ev.size()) {
-        (void)hipEventRecord(p->ev[p->ev_used], st);
-        const int rc = launch();
-        (void)hipEventRecord(p->ev[p->ev_used + 1], st);
-        p->ev_site[p->ev_used / 2] = site;
-        p->ev_used += 2;
-        return rc;
-    }
-    if (p->timing) p->ev_overflow = true;
-    return launch();
+    if (!p->timing) return launch();
+    if (p->ev_live == F5_EV_RING) timing_fold(p, F5_EV_RING / 2);
+    const size_t i = (p->ev_head + p->ev_live) % F5_EV_RING;
+    (void)hipEventRecord(p->ev[2 * i], st);
+    const int rc = launch();
+    (void)hipEventRecord(p->ev[2 * i + 1], st);
+    p->ev_site[i] = site;
+    ++p->ev_live;
+    return rc;
 }
+
+static int finish_if_pending(f5_plan_s* p);  // completes a deferred sample() before the plan's buffers are reused (defined with f5_sample)
 
 // ----------------------------------------------------------------------------- model
 static void add_slot(SlotMap& s, const std::string& name, std::vector<int64_t> shape) { s[name].shape = std::move(shape); }
@@ -744,13 +765,18 @@ extern "C" int f5_plan_get_option(f5_plan_t p, const char* key, int* value) {
 }
 
 extern "C" int f5_plan_timing_begin(f5_plan_t p, int max_launches) {
+    // max_launches: kept for ABI compatibility (round 1-3 sized an event pool with it); the ring is bounded whatever the call count
     if (!p || max_launches <= 0) return f5_fail(F5_EINVAL, "bad argument");
-    for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
-    p->ev.assign((size_t)max_launches * 2, nullptr);
-    p->ev_site.assign((size_t)max_launches, 0);
-    for (auto& e : p->ev) F5_HIP(hipEventCreate(&e));
-    p->ev_used = 0;
-    p->ev_overflow = false;
+    if (p->ev.empty()) {
+        p->ev.assign(2 * F5_EV_RING, nullptr);
+        p->ev_site.assign(F5_EV_RING, 0);
+        for (auto& e : p->ev) F5_HIP(hipEventCreate(&e));
+    }
+    p->ev_head = p->ev_live = 0;
+    for (int s = 0; s < F5_SITE_COUNT; ++s) {
+        p->site_ms[s] = 0.0;
+        p->site_n[s] = 0;
+    }
     p->timing = true;
     return 0;
 }
@@ -759,26 +785,9 @@ extern "C" int f5_plan_timing_end(f5_plan_t p, float* avg_ms, int* launches, f5_
     if (!p || !avg_ms || !launches) return f5_fail(F5_EINVAL, "null argument");
     p->timing = false;
     F5_HIP(hipStreamSynchronize((hipStream_t)stream));
-    for (int s = 0; s < F5_SITE_COUNT; ++s) {
-        p->site_ms[s] = 0.0;
-        p->site_n[s] = 0;
-    }
-    for (size_t i = 0; i + 1 < p->ev_used; i += 2) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]) == hipSuccess) {
-            p->site_ms[p->ev_site[i / 2]] += ms;
-            ++p->site_n[p->ev_site[i / 2]];
-        }
-    }
-    for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
-    p->ev.clear();
-    p->ev_used = 0;
+    timing_fold(p, p->ev_live);
     *avg_ms = p->site_n[F5_SITE_QKV] ? (float)(p->site_ms[F5_SITE_QKV] / p->site_n[F5_SITE_QKV]) : 0.f;
     *launches = p->site_n[F5_SITE_QKV];
-    if (p->ev_overflow) {
-        p->ev_overflow = false;
-        return f5_fail(F5_ESTATE, "f5_plan_timing_begin's max_launches was too small: launches beyond it were not timed (7 per block + 3 per evaluation)");
-    }
     return 0;
 }
 
@@ -1318,6 +1327,7 @@ extern "C" int f5_dit_forward(f5_plan_t p, int B, int N, const float* x, const f
     F5_TRY(check_plan_shape(p, B, N));
     if (!x || !cond || !text_embed || !time || !out) return f5_fail(F5_EINVAL, "null argument");
     if (p->m->cfg.backbone == F5_BACKBONE_MMDIT) return f5_fail(F5_ENOTSUP, "MMDiT: the text stream has its own length, call f5_mmdit_forward");
+    F5_TRY(finish_if_pending(p));
     hipStream_t st = (hipStream_t)stream;
     f5_model_s* m = p->m;
     p->mod_tv.clear();  // p->mod is overwritten with per-sample times
@@ -1521,6 +1531,15 @@ static int stage_time_grid(f5_plan_s* p, const float* tgrid_host, int steps, int
     return launch_set_floats(p->coefs, cf.data(), nev, st);
 }
 
+// A plan holds ONE deferred sample(): its staged inputs and the device flag words would be overwritten by the next call.  Every entry point
+// that reuses the plan's buffers completes the deferred call first (on the stream it was enqueued on), so a raised range-guard flag is never
+// lost when a caller round-robins more chunks than it has streams.
+extern "C" int f5_sample_finish(f5_plan_t p, f5_stream_t stream);
+static int finish_if_pending(f5_plan_s* p) {
+    if (p && p->pending.valid) return f5_sample_finish(p, (f5_stream_t)p->pending.stream);
+    return 0;
+}
+
 extern "C" int f5_sample(f5_plan_t p, int B, int N, const float* cond, const int32_t* text, int nt, const int32_t* lens,
                          const int32_t* durations, const float* y0, const float* tgrid_host, int steps, float cfg_strength, int ode_method,
                          float* out, float* trajectory, int use_graph, f5_stream_t stream) {
@@ -1530,6 +1549,7 @@ extern "C" int f5_sample(f5_plan_t p, int B, int N, const float* cond, const int
     if (ode_method != F5_ODE_EULER && ode_method != F5_ODE_MIDPOINT) return f5_fail(F5_EINVAL, "bad ode_method");
     const int nev = ode_method == F5_ODE_MIDPOINT ? 2 * steps : steps;
     if (nev > p->maxE) return f5_fail(F5_EINVAL, "%d evaluations exceed the plan's max_evals=%d", nev, p->maxE);
+    F5_TRY(finish_if_pending(p));
     hipStream_t st = (hipStream_t)stream;
     f5_model_s* m = p->m;
     const int mel = m->cfg.mel_dim, bn = B * N;
@@ -1552,7 +1572,7 @@ extern "C" int f5_sample(f5_plan_t p, int B, int N, const float* cond, const int
     if (guarded && p->sat_check == 2) {
         // deferred guard (plan option "residual_guard" = 2): nothing synchronises here, so several plans can be fed on several streams from
         // one host thread; f5_sample_finish reads the flag later and repeats the loop if it must (the inputs stay staged in the plan)
-        p->pending = PendingSample{true, a, use_graph, out, trajectory};
+        p->pending = PendingSample{true, a, use_graph, out, trajectory, st};
     } else if (guarded) {
         F5_TRY(guard_check_and_fallback(p, a, use_graph, st));
     }
@@ -1637,6 +1657,7 @@ extern "C" int f5_sample_ragged(f5_plan_t p, int B, const int32_t* frames_host, 
     const size_t bn_cap = (size_t)p->maxB * p->maxN;
     if ((size_t)rg.T > bn_cap || 2 * (size_t)rg.T > p->rows_cap || (size_t)(B + 1) * nt > bn_cap)
         return f5_fail(F5_EINVAL, "%d rows (frames + gaps) exceed the plan (max_batch x max_seq = %zu)", rg.T, bn_cap);
+    F5_TRY(finish_if_pending(p));
     hipStream_t st = (hipStream_t)stream;
     const int mel = m->cfg.mel_dim, D = m->cfg.dim, td = m->cfg.text_dim, T = rg.T;
     F5_TRY(stage_time_grid(p, tgrid_host, steps, ode_method, st));

@@ -37,14 +37,19 @@ def gather_utterances(local: List[torch.Tensor], frame_counts: List[int], mel_di
         all_frame_counts = [None] * world
         dist.all_gather_object(all_frame_counts, [int(c) for c in frame_counts])
     rank = dist.get_rank()
-    assert [int(c) for c in all_frame_counts[rank]] == [int(c) for c in frame_counts], "frame counts of this rank disagree with the metadata"
+    # a rank whose own counts disagree with the agreed metadata must not skip the collective (the other ranks would wait in it for ever):
+    # it sends a payload of the agreed shape and raises afterwards
+    agreed = [int(c) for c in all_frame_counts[rank]] == [int(c) for c in frame_counts]
     max_items = max(len(c) for c in all_frame_counts)
     max_frames = max((max(c) for c in all_frame_counts if len(c)), default=0)
     payload = torch.zeros(max_items, max_frames, mel_dim, device=device, dtype=torch.float32)
-    for i, t in enumerate(local):
-        payload[i, : t.shape[0]] = t
+    for i, t in enumerate(local[:max_items]):
+        n = min(t.shape[0], max_frames)
+        payload[i, :n] = t[:n]
     gathered = [torch.zeros_like(payload) for _ in range(world)]
     dist.all_gather(gathered, payload)  # the single data collective of the whole path (RCCL over xGMI under backend "nccl")
+    if not agreed:
+        raise RuntimeError(f"rank {rank}: frame counts {list(map(int, frame_counts))} disagree with the metadata {list(map(int, all_frame_counts[rank]))}")
     out = []
     for r in range(world):
         for i, n in enumerate(all_frame_counts[r]):
@@ -53,9 +58,19 @@ def gather_utterances(local: List[torch.Tensor], frame_counts: List[int], mel_di
 
 
 def _generated_frames(kw) -> List[int]:
-    """frames sample() returns for each utterance of one batch: out[i, lens_i:duration_i] (eval_infer_batch.py:185)."""
-    lens, dur = kw["lens"], kw["duration"]
-    return [int(dur[i]) - int(lens[i]) for i in range(len(lens))]
+    """frames of ``out[i, lens_i:duration_i]`` (eval_infer_batch.py:185) for each utterance of one batch, with the clamping CFM.sample applies
+    (cfm.py:127-135): out has max_i(min(max(max(n_text_i, lens_i) + 1, duration_i), max_duration)) rows, and a slice never has fewer than 0."""
+    lens, dur, text = kw["lens"], kw["duration"], kw.get("text")
+    max_duration = int(kw.get("max_duration", 4096))
+    b = len(lens)
+    if torch.is_tensor(text):
+        ntext = [int((text[i] != -1).sum()) for i in range(b)]
+    elif text is not None:
+        ntext = [len(t) for t in text]
+    else:
+        ntext = [0] * b
+    rows = max(min(max(max(ntext[i], int(lens[i])) + 1, int(dur[i])), max_duration) for i in range(b))
+    return [max(0, min(int(dur[i]), rows) - min(int(lens[i]), rows)) for i in range(b)]
 
 
 @torch.no_grad()

@@ -108,6 +108,9 @@ class F5TTSWrapper:
         # (0 = off: chunks run one per stream as above).  Applies when every chunk has at least 256 frames (the row count from which a batch-1
         # call takes the tuned kernels too, so both paths compute bit-identical mels).
         self.ragged_chunks = int(os.environ.get("F5HIP_RAGGED_CHUNKS", "8"))
+        # "cpu": draw every chunk's initial noise from torch's CPU generator, in chunk order -- the numbers the reference's CPU path draws after
+        # the same torch.manual_seed (reference model/cfm.py:178-183 with device = cpu); None = on the GPU, as the reference's GPU path does
+        self.model.noise_device = os.environ.get("F5HIP_NOISE_DEVICE") or None
         self.nfe_step = 32
         self.cfg_strength = 2.0
         self.sway_sampling_coef = -1.0

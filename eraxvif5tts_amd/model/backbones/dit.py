@@ -198,6 +198,7 @@ class DiT(nn.Module):
         stream = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0
         for (st, b, n, e), h in self._plans:
             if st == stream and b >= batch and n >= seq and e >= evals:
+                self._finish_plan(h)  # a deferred sample() still owns this plan's staged inputs and flag words: complete it first
                 return h
         lib = _lib.load()
         seq_cap = min(4096, -(-seq // 64) * 64)
@@ -206,7 +207,7 @@ class DiT(nn.Module):
         mine = [i for i, (k, _) in enumerate(self._plans) if k[0] == stream]
         while len(mine) >= 2 or (len(self._plans) >= 12 and mine):  # keep HBM use bounded: at most two buckets per stream
             key, old = self._plans.pop(mine.pop(0))
-            self._pending.pop(old.value, None)
+            self._finish_plan(old)  # never destroy a plan whose deferred sample() is still in flight
             lib.f5_plan_destroy(old)
             mine = [i for i, (k, _) in enumerate(self._plans) if k[0] == stream]
         self._plans.append(((stream, batch, seq_cap, max(evals, 1)), h))
@@ -311,8 +312,11 @@ class DiT(nn.Module):
             raise NotImplementedError("ragged sampling is built for the DiT backbone")
         B = len(frames)
         evals = steps * (2 if method == "midpoint" else 1)
-        seq = max(max(frames), int(text.shape[1])) + 32  # (rows per utterance incl. its zero gap, rounded: <= seq_cap of plan())
-        plan = self.plan(B, seq, evals)
+        # the plan must hold T = sum(round_up(n_i + 16, 16)) rows per CFG half and (B + 1) text rows: size it by total rows, not by the longest
+        # utterance (seq is capped at 4096 by plan(), so utterances near that length need a larger batch dimension)
+        seq = min(4096, -(-(max(max(frames), int(text.shape[1])) + 32) // 64) * 64)
+        rows = sum(-(-(int(f) + 16) // 16) * 16 for f in frames)
+        plan = self.plan(max(B, -(-rows // seq), -(-(B + 1) * int(text.shape[1]) // seq)), seq, evals)
         dev = "cuda"
         cond_cat = cond_cat.to(device=dev, dtype=torch.float32).contiguous()
         y0_cat = y0_cat.to(device=dev, dtype=torch.float32).contiguous()
@@ -329,6 +333,17 @@ class DiT(nn.Module):
                                         _lib.stream_ptr()), "sample_ragged")
         self._report_fallback(lib, plan)
         return out
+
+    def _finish_plan(self, plan):
+        """Complete the deferred sample() of ONE plan, if it has one (plan reuse, eviction)."""
+        ent = self._pending.pop(plan.value, None)
+        if ent is None:
+            return
+        lib = _lib.load()
+        _, stream = ent
+        with torch.cuda.stream(stream):
+            _lib.check(lib.f5_sample_finish(plan, C.c_void_p(stream.cuda_stream)), "sample_finish")
+        self._report_fallback(lib, plan)
 
     def finish_pending(self):
         """Complete every sample() issued with defer_guard=True: synchronise its stream, read the range-guard flag and let the library repeat

@@ -31,6 +31,10 @@ class CFM(nn.Module):
         self.sigma = sigma
         self.odeint_kwargs = odeint_kwargs
         self.vocab_char_map = vocab_char_map
+        # where sample() draws its initial noise when none is given: None = on the model's device, as the reference does (cfm.py:182: a GPU
+        # run uses the device generator); "cpu" = from torch's CPU generator and then moved, i.e. the numbers the reference's CPU path draws
+        # for the same torch.manual_seed / seed= (end-to-end parity runs against the CPU oracle)
+        self.noise_device = None
 
     @property
     def device(self):
@@ -42,9 +46,10 @@ class CFM(nn.Module):
     @torch.no_grad()
     def sample(self, cond, text, duration, *, lens=None, steps=32, cfg_strength=1.0, sway_sampling_coef=None, seed=None,
                max_duration=4096, vocoder=None, no_ref_audio=False, duplicate_test=False, t_inter=0.1, edit_mask=None,
-               y0=None, return_trajectory=True, use_graph="auto", defer_guard=False):
+               y0=None, return_trajectory=True, use_graph="auto", defer_guard=False, noise_device=None):
         """Same arguments and return value ``(out, trajectory)`` as the reference.  Extra keyword-only knobs:
-        ``y0`` (explicit initial noise, zero-padded [b, N, mel]: parity tests), ``return_trajectory=False`` skips
+        ``y0`` (explicit initial noise, zero-padded [b, N, mel]: parity tests), ``noise_device`` ("cpu": draw the noise as the reference's
+        CPU path does, cfm.py:178-183 with self.device = cpu; default ``self.noise_device``, None = the model's device), ``return_trajectory=False`` skips
         materialising the [steps+1, b, N, mel] trajectory (returned as None), ``use_graph`` = True / False / "auto" (default: replay a hipGraph from the second call with the same shape on),
         ``defer_guard=True`` returns without the call's one stream synchronisation (several sample() calls can then be in flight on several
         streams); ``transformer.finish_pending()`` completes them."""
@@ -84,12 +89,13 @@ class CFM(nn.Module):
         mask = lens_to_mask(duration) if batch > 1 else None  # single inference needs no mask (cfm.py:152-155)
 
         if y0 is None:
+            ndev = default(default(noise_device, self.noise_device), self.device)
             rows = []
             for dur in duration:
                 if exists(seed):
                     torch.manual_seed(seed)
-                rows.append(torch.randn(int(dur), self.num_channels, device=self.device, dtype=step_cond.dtype))
-            y0 = pad_sequence(rows, padding_value=0, batch_first=True)
+                rows.append(torch.randn(int(dur), self.num_channels, device=ndev, dtype=step_cond.dtype))
+            y0 = pad_sequence(rows, padding_value=0, batch_first=True).to(device)
         else:
             y0 = y0.to(device=device, dtype=step_cond.dtype)
 
@@ -123,7 +129,7 @@ class CFM(nn.Module):
 
     @torch.no_grad()
     def sample_ragged(self, cond, texts, durations, *, lens=None, steps=32, cfg_strength=1.0, sway_sampling_coef=None, seed=None,
-                      max_duration=4096, y0s=None):
+                      max_duration=4096, y0s=None, noise_device=None):
         """``sample()`` for several texts over ONE prompt, each with its own duration, in one set of kernel launches without padding the
         utterances to a common length (libf5hip ``f5_sample_ragged``).  Equivalent to ``[sample(cond, [t], d)[0] for t, d in zip(texts,
         durations)]`` -- the reference's batch-1 arithmetic per utterance (cfm.py:82-208 with batch = 1: no key mask), noise drawn in the
@@ -154,6 +160,7 @@ class CFM(nn.Module):
         duration = torch.maximum(torch.maximum((text != -1).sum(dim=-1), lens) + 1, duration).clamp(max=max_duration)  # cfm.py:127-131
         frames = [int(d) for d in duration]
         conds, noises = [], []
+        ndev = default(default(noise_device, self.noise_device), self.device)
         for i, n in enumerate(frames):
             conds.append(F.pad(cond[i if cond.shape[0] > 1 else 0], (0, 0, 0, n - cond_seq_len), value=0.0))
             if y0s is not None:
@@ -161,7 +168,7 @@ class CFM(nn.Module):
             else:
                 if exists(seed):
                     torch.manual_seed(seed)
-                noises.append(torch.randn(n, self.num_channels, device=self.device, dtype=cond.dtype))
+                noises.append(torch.randn(n, self.num_channels, device=ndev, dtype=cond.dtype).to(device))
         t = torch.linspace(0, 1, steps + 1, device=self.device, dtype=cond.dtype)
         if sway_sampling_coef is not None:
             t = t + sway_sampling_coef * (torch.cos(torch.pi / 2 * t) - 1 + t)

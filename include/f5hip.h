@@ -171,8 +171,8 @@ F5_API int f5_plan_set_tap(f5_plan_t p, const char* stage, float* dst);
 F5_API int f5_plan_timing_begin(f5_plan_t p, int max_launches);
 F5_API int f5_plan_timing_end(f5_plan_t p, float* avg_ms, int* launches, f5_stream_t stream);
 /* the same measurement for every kernel of a DiT evaluation: after f5_plan_timing_end, mean device time per launch of call site
- * `site` (max_launches of f5_plan_timing_begin counts event pairs over ALL sites: 7 per block + 3 per evaluation; when the pool runs out
- * f5_plan_timing_end fails with F5_ESTATE instead of returning means over the early launches only). */
+ * `site`.  The event pairs live in a bounded ring of 512 pairs created once per plan (round 4; `max_launches` is accepted and ignored): when
+ * the ring is full its older half is folded into the per-site sums, so any number of launches is covered with 1 024 live events. */
 #define F5_SITE_QKV 0   /* fused QKV projection + RoPE            modules.py:452-461 */
 #define F5_SITE_ATTN 1  /* scaled-dot-product attention           modules.py:483-497 */
 #define F5_SITE_OUT 2   /* attention out-projection x gate_msa    modules.py:499-501,635 */

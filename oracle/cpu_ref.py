@@ -662,6 +662,48 @@ def vocos_decode(V, mel):
     return istft_center(mag * torch.cos(ph), mag * torch.sin(ph))
 
 
+# ----------------------------------------------------------------------------- a1: the composed generate() chain
+def cross_fade_concat(waves, cross_fade_duration, sr=24000):
+    """f5tts_wrapper.py:541-575: linear cross-fade of consecutive chunk waveforms (numpy, float64 ramps as np.linspace gives them)."""
+    import numpy as np
+    if cross_fade_duration <= 0:
+        return np.concatenate(waves)
+    final = waves[0]
+    for nxt in waves[1:]:
+        n = min(int(cross_fade_duration * sr), len(final), len(nxt))
+        if n <= 0:
+            final = np.concatenate([final, nxt])
+            continue
+        final = np.concatenate([final[:-n], final[-n:] * np.linspace(1, 0, n) + nxt[:n] * np.linspace(0, 1, n), nxt[n:]])
+    return final
+
+
+def generate_chain(W, cfg, V, ref_audio, ref_text_nbytes, chunks, *, nfe_step=32, cfg_strength=2.0, sway_sampling_coef=-1.0, speed=1.0,
+                   cross_fade_duration=0.15, target_rms=0.1, hop=256, sr=24000, method="euler"):
+    """F5TTSWrapper.generate (f5tts_wrapper.py:476-575) as the reference's CPU path runs it, from the stored prompt waveform on:
+    prompt mel (modules.py:75-101) -> per text chunk: duration rule (:500-504), CFM.sample (cfm.py:82-208; the initial noise is drawn from
+    torch's GLOBAL CPU generator, one randn(duration, 100) per chunk in chunk order, cfm.py:178-183 without a seed) -> cut at ref_audio_len
+    (:519) -> Vocos.decode (:524) -> rms rule on the stored prompt (:529-531) -> cross-fade (:541-575).
+    ref_audio [1, nw] f32 at 24 kHz (the wrapper's ref_audio_processed); chunks = [(token ids [1, nt] incl. the reference text, number of utf-8
+    bytes of the chunk's own text)].  Returns (wave, [mel [100, frames] per chunk])."""
+    ref_audio_len = ref_audio.shape[-1] // hop
+    cond = mel_spectrogram(ref_audio).permute(0, 2, 1)  # cfm.py:110-112: a raw-wave prompt becomes [1, nw // hop + 1, 100]
+    waves, mels = [], []
+    for ids, gen_nbytes in chunks:
+        local_speed = 0.3 if gen_nbytes < 10 else speed
+        duration = ref_audio_len + int(ref_audio_len / ref_text_nbytes * gen_nbytes / local_speed)
+        out, _ = sample(W, cfg, cond, ids, duration, steps=nfe_step, cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef,
+                        method=method, return_trajectory=False)
+        gen = out.float()[:, ref_audio_len:, :].permute(0, 2, 1)
+        wave = vocos_decode(V, gen)
+        rms = torch.sqrt(torch.mean(torch.square(ref_audio)))
+        if rms < target_rms:
+            wave = wave * rms / target_rms
+        waves.append(wave.squeeze().numpy())
+        mels.append(gen.squeeze(0).numpy())
+    return cross_fade_concat(waves, cross_fade_duration, sr), mels
+
+
 # ----------------------------------------------------------------------------- duration predictor (SURVEY 8f-2)
 def duration_predictor(W, tokens, mask, add_one=True, prefix="", g_cond=None):
     """DurationPredictor.forward (model/duration_predictor.py:28-46; phoneme_forward :48-68 with add_one=False):
@@ -734,6 +776,26 @@ def random_dit_weights(cfg, vocab_size, seed=0, mel_dim=100):
             fan_in = math.prod(shape[1:])
             W[name] = torch.randn(shape, generator=g) / math.sqrt(fan_in)
     return W
+
+
+def fwd_1024_inputs(which):
+    """Inputs of base_fwd_1024.npz, regenerated from seeds by the tests (CPU generator: deterministic), so only outputs are stored.
+    which = "b1": B = 1, N = 1024, no key mask (cfm.py:152-155: batch 1 builds none) -- the single-utterance production shape;
+    which = "b2": B = 2, N = 1000, durations 1000 / 870 (key mask; ragged 256-row tiles, partial attention key tiles)."""
+    V = 2545
+    g = torch.Generator().manual_seed({"b1": 1024, "b2": 1000}[which])
+    B, N, dur = (1, 1024, [1024]) if which == "b1" else (2, 1000, [1000, 870])
+    nc = N // 3
+    x = torch.randn(B, N, 100, generator=g)
+    cond = (torch.randn(B, N, 100, generator=g) * 2 - 3).clamp(float(math.log(1e-5)), 3.0)
+    cond[:, nc:] = 0
+    text = torch.randint(0, V, (B, N // 6), generator=g)
+    if B > 1:
+        text[1, 140:] = -1
+        x[1, dur[1]:] = 0
+    mask = None if B == 1 else lens_to_mask(torch.tensor(dur))
+    t = torch.tensor({"b1": 0.6180, "b2": 0.1415}[which])
+    return x, cond, text, mask, t, dur
 
 
 def random_vocos_weights(seed=0, dim=512, inter=1536, layers=8, n_mels=100, n_fft=1024):

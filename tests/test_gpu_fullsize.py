@@ -481,3 +481,52 @@ def test_c1_config_matches_oracle(prec):
                             return_trajectory=False, use_graph=use_graph)
         n_ref = int(lens[0])
         assert rel_l2(out.cpu()[:, n_ref:], ref[:, n_ref:]) < tol, (prec, use_graph)
+
+
+@pytest.fixture(scope="module")
+def base_models():
+    """true-size F5TTS_Base with the weights of tests/golden/base_fwd*.npz (seed 20250101), one upload per precision for the whole module;
+    created under F5HIP_GEMM_KERNEL = F5HIP_ATTN_KERNEL = 1: the tuned kernels are forced wherever they support the problem."""
+    import os
+
+    import gpu_helpers as G
+    from oracle import cpu_ref
+    cfg = dict(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, text_mask_padding=False, conv_layers=4, pe_attn_head=1)
+    W = cpu_ref.random_dit_weights(cfg, 2545, seed=20250101)
+    made = {}
+
+    def get(prec):
+        if prec not in made:
+            old = {k: os.environ.get(k) for k in ("F5HIP_GEMM_KERNEL", "F5HIP_ATTN_KERNEL")}
+            os.environ.update(F5HIP_GEMM_KERNEL="1", F5HIP_ATTN_KERNEL="1")
+            try:
+                made[prec] = G.make_dit(cfg, 2545, W, prec)
+                made[prec].plan(2, 1024, 1)
+            finally:
+                for k, v in old.items():
+                    os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        return made[prec]
+    return get
+
+
+@pytest.mark.parametrize("which", ["b1", "b2"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_true_size_forward_at_production_length_matches_reference(base_models, prec, which):
+    """tests/golden/base_fwd_1024.npz: the reference's OWN true-size F5TTS_Base evaluated once at the production sequence length -- B = 1,
+    N = 1024 (no key mask: the single-utterance shape) and B = 2, N = 1000 with durations 1000 / 870 (key mask, ragged 256-row tiles, a partial
+    last attention tile) -- both CFG branches, against the HIP path with the tuned GEMM / attention / conv / LayerNorm kernels forced.
+    Tolerances as everywhere: fp32 mode rel-L2 <= 1e-4 per evaluation, bf16 mode <= 1.5e-2 (valid rows)."""
+    from conftest import load_golden
+    from oracle import cpu_ref
+    z = load_golden("base_fwd_1024")
+    m = base_models(prec)
+    x, cond, text, mask, t, dur = cpu_ref.fwd_1024_inputs(which)
+    assert float(x.double().sum()) == float(z[which + ".x_sum"]) and float(cond.double().sum()) == float(z[which + ".cond_sum"])
+    valid = torch.arange(x.shape[1])[None, :] < torch.tensor(dur)[:, None]
+    for drop, key in ((False, "out_c"), (True, "out_u")):
+        out = m(x=x.cuda(), cond=cond.cuda(), text=text.cuda(), time=t.cuda(), mask=None if mask is None else mask.cuda(),
+                drop_audio_cond=drop, drop_text=drop).cpu()
+        ref = torch.from_numpy(z[f"{which}.{key}"])
+        err = rel_l2(out[valid], ref[valid])
+        print(f"base_fwd_1024 {which} {key} [{prec}]: rel-L2 {err:.2e}")
+        assert err < {"fp32": 1e-4, "bf16": 1.5e-2}[prec], (which, key)

@@ -197,6 +197,59 @@ def test_wrapper_end_to_end(tmp_path):
         tts.calculate_duration_with_predictor(torch.tensor([[5, 6, 7]], device="cuda"), torch.tensor([3], device="cuda"))
 
 
+@pytest.mark.parametrize("prec,ragged", [("fp32", True), ("fp32", False), ("bf16", True)])
+def test_generate_end_to_end_matches_the_oracle_chain(tmp_path, prec, ragged):
+    """a1 as a whole (f5tts_wrapper.py:408-607): wav file -> preprocess_reference -> generate() with two text chunks (so the cross-fade fires) on the HIP
+    path, against the CPU oracle chain cpu_ref.generate_chain = mel_spectrogram -> CFM.sample -> Vocos.decode -> rms rule -> cross-fade on the same
+    wav / text / seed.  The noise is drawn as the reference's CPU path draws it (torch's CPU generator, one randn per chunk in chunk order:
+    `noise_device = "cpu"`), so both sides start from the same y0 after the same torch.manual_seed.
+    Stated tolerances: generated mel rel-L2 <= 2e-4 (fp32 mode) / 2e-2 (bf16 mode), as everywhere; waveform rel-L2 <= 2e-3 (fp32) / 1e-1 (bf16):
+    Vocos exponentiates its head (exp, clip 1e2), which amplifies a mel deviation by about 5x at these sizes."""
+    from eraxvif5tts_amd.infer import audio
+    from eraxvif5tts_amd.infer.f5tts_wrapper import F5TTSWrapper
+    from eraxvif5tts_amd.infer.utils_infer import chunk_text
+    from eraxvif5tts_amd.model.utils import convert_char_to_pinyin, list_str_to_idx
+    arch = dict(dim=128, depth=2, heads=2, ff_mult=2, text_dim=64, conv_layers=2, pe_attn_head=1, text_mask_padding=False)
+    V = 32
+    W = cpu_ref.random_dit_weights(arch, V, seed=25)
+    hp = dict(dim=64, intermediate_dim=128, num_layers=2)
+    VW = cpu_ref.random_vocos_weights(seed=26, dim=64, inter=128, layers=2)
+    cfg_path, ckpt, vdir, vocab = _write_tiny_assets(str(tmp_path), arch, V, W, hp, VW)
+    sr = 24000
+    t = np.arange(int(2.0 * sr)) / sr
+    wav = 0.03 * np.sin(2 * np.pi * 190 * t + 0.7) * (1 + 0.3 * np.sin(2 * np.pi * 5 * t)) + 0.01 * np.sin(2 * np.pi * 1370 * t)
+    ref_wav = os.path.join(str(tmp_path), "ref.wav")
+    audio.write_wav(ref_wav, wav, sr)
+    # the stored prompt, computed independently: 16-bit PCM as read back, + 50 ms of silence (:313), boosted to rms 0.1 (:334-336)
+    pcm = np.clip(np.round(wav * 32767.0), -32768, 32767).astype(np.float32) / np.float32(32768.0)
+    prompt = torch.from_numpy(np.concatenate([pcm, np.zeros(int(0.05 * sr), np.float32)]))[None]
+    prompt = prompt * 0.1 / torch.sqrt(torch.mean(torch.square(prompt)))
+
+    tts = F5TTSWrapper(model_name=cfg_path, ckpt_path=ckpt, vocab_file=vocab, use_local_vocoder=True, vocoder_path=vdir, precision=prec)
+    tts.model.noise_device = "cpu"
+    if not ragged:
+        tts.ragged_chunks = 0
+    aud, ref_text = tts.preprocess_reference(ref_wav, "a quiet tone")
+    assert aud.shape == prompt.shape and (aud.cpu() - prompt).abs().max() < 1e-6
+    text = "hello there, this is a test. " * 3 + "and one more sentence to force a second chunk, because the budget is small."
+    max_chars = int(len(ref_text.encode()) / (prompt.shape[-1] / sr) * (22 - prompt.shape[-1] / sr))
+    chunks = chunk_text(text, max_chars=max_chars)
+    assert len(chunks) == 2
+    torch.manual_seed(1234)
+    wave, rate, spec = tts.generate(text, nfe_step=4, return_numpy=True, return_spectrogram=True)
+
+    vmap = tts.vocab_char_map
+    oracle_chunks = [(list_str_to_idx(convert_char_to_pinyin([ref_text + c]), vmap), len(c.encode("utf-8"))) for c in chunks]
+    torch.manual_seed(1234)
+    ref_wave, ref_mels = cpu_ref.generate_chain(W, arch, VW, prompt, len(ref_text.encode("utf-8")), oracle_chunks, nfe_step=4)
+    ref_spec = np.concatenate(ref_mels, axis=1)
+    assert spec.shape == ref_spec.shape and wave.shape == ref_wave.shape and min(m.shape[1] for m in ref_mels) >= 256
+    mel_err, wave_err = rel_l2(spec, ref_spec), rel_l2(wave, ref_wave)
+    print(f"generate() vs oracle chain [{prec}, ragged={ragged}]: mel rel-L2 {mel_err:.2e}, wave rel-L2 {wave_err:.2e}")
+    assert mel_err < {"fp32": 2e-4, "bf16": 2e-2}[prec]
+    assert wave_err < {"fp32": 2e-3, "bf16": 1e-1}[prec]
+
+
 def test_infer_process_batch_process_and_safetensors_checkpoint(tmp_path, monkeypatch):
     """utils_infer.load_model on a .safetensors EMA checkpoint (reference utils_infer.py:184-226, f5tts_wrapper.py:224-229),
     infer_process / infer_batch_process (reference utils_infer.py:366-563): chunk bookkeeping, the streaming generator, and the

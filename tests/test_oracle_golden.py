@@ -97,6 +97,21 @@ def test_true_size_base_forward(fixture, v1):
         assert rel_l2(out, z[key]) < 5e-5, key
 
 
+@pytest.mark.parametrize("which", ["b1", "b2"])
+def test_true_size_base_forward_at_production_length(which):
+    """base_fwd_1024.npz: the reference's own true-size F5TTS_Base evaluated once at N = 1024 (B = 1, no mask) and N = 1000 (B = 2, key mask);
+    inputs regenerated from seeds (checksums stored), outputs from the reference."""
+    z = load_golden("base_fwd_1024")
+    cfg = dict(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, text_mask_padding=False, conv_layers=4, pe_attn_head=1)
+    W = cpu_ref.random_dit_weights(cfg, int(z["vocab"]), seed=int(z["seed"]))
+    x, cond, text, mask, t, _ = cpu_ref.fwd_1024_inputs(which)
+    assert float(x.double().sum()) == float(z[which + ".x_sum"]) and float(cond.double().sum()) == float(z[which + ".cond_sum"])
+    assert int(text.sum()) == int(z[which + ".text_sum"])
+    for drop, key in ((False, "out_c"), (True, "out_u")):
+        out = cpu_ref.dit_forward(W, cfg, x, cond, text, t, drop, drop, mask=mask)
+        assert rel_l2(out, z[f"{which}.{key}"]) < 5e-5, key
+
+
 def _unett_case(z, tag):
     import ast
     arch = ast.literal_eval(str(z[f"{tag}.arch"]))

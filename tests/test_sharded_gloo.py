@@ -71,3 +71,18 @@ def test_two_rank_gather_matches_single_process():
         for a, b in zip(results[rank], single):
             a = torch.from_numpy(a)
             assert a.shape == b.shape and torch.equal(a, b)
+
+
+def test_gather_metadata_follows_the_sampler_clamping():
+    """the locally derived frame counts must equal len(out[i, lens_i:duration_i]) for what CFM.sample returns (cfm.py:127-135: at least
+    max(n_text, lens) + 1 rows, at most max_duration; the requested duration may exceed the rows that exist, lens may exceed the duration)."""
+    from eraxvif5tts_amd.eval.sharded import _generated_frames
+    text = torch.full((3, 12), -1)
+    text[0, :5] = 1
+    text[1, :12] = 1
+    text[2, :3] = 1
+    kw = dict(text=text, lens=torch.tensor([4, 6, 9]), duration=torch.tensor([5000, 8, 7]), max_duration=40)
+    eff = torch.maximum(torch.maximum((text != -1).sum(-1), kw["lens"]) + 1, kw["duration"]).clamp(max=40)
+    out = torch.zeros(3, int(eff.max()), 100)
+    want = [out[i, int(kw["lens"][i]): int(kw["duration"][i])].shape[0] for i in range(3)]
+    assert _generated_frames(kw) == want == [36, 2, 0]
