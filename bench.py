@@ -437,12 +437,24 @@ def main():
     gathered = [torch.zeros(bmax, N, 100, device=dev) for _ in range(world)] if world > 1 else None
     pad = torch.zeros(bmax, N, 100, device=dev) if world > 1 else None
 
+    # N > 1: HIP events (on the stream the sampler's launches and the collective are enqueued on) split every step into this rank's
+    # sample() and the all_gather behind it, so that one record separates per-GPU batch efficiency, rank skew and gather time
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)] if world > 1 else None
+    tick = {"i": -1}
+
     def step():
+        e = ev[tick["i"]] if (world > 1 and 0 <= tick["i"] < args.steps) else None
+        if e:
+            e[0].record()
         out, _ = cfm.sample(cond=cond, text=text, duration=duration, lens=lens, steps=nfe, cfg_strength=args.cfg,
                             sway_sampling_coef=-1.0, seed=0, return_trajectory=False, use_graph=not args.no_graph)
         if world > 1:
+            if e:
+                e[1].record()
             pad[:B].copy_(out)
             dist.all_gather(gathered, pad)  # the only collective of the path: finished mels over RCCL/xGMI
+            if e:
+                e[2].record()
         return out
 
     debug = bool(os.environ.get("F5_BENCH_DEBUG"))
@@ -458,15 +470,18 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        tick["i"] = i
         out = step()
         if debug:
             sys.stderr.write(f"[debug] step {i}: residual fallbacks so far {model.residual_fallbacks()}\n")
     torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0  # this rank's own work, before it waits for the others
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     devices = [torch.cuda.get_device_name(dev)]
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -474,6 +489,23 @@ def main():
         names = [None] * world
         dist.all_gather_object(names, f"rank{rank}:cuda{torch.cuda.current_device()}:{devices[0]}")
         devices = names
+        # after the timed region: the collective alone, every rank entering it together (no skew inside the measurement)
+        tick["i"] = -1
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist.barrier()
+        torch.cuda.synchronize()
+        g0.record()
+        for _ in range(5):
+            dist.all_gather(gathered, pad)
+        g1.record()
+        torch.cuda.synchronize()
+        mine_rec = {"rank": rank, "utterances": B, "elapsed_s": round(own_elapsed, 6),
+                    "sample_ms": round(sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps, 3),
+                    "gather_ms_in_step": round(sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps, 3),  # includes waiting for slower ranks
+                    "gather_only_ms": round(g0.elapsed_time(g1) / 5, 3),
+                    "mel_frames_per_s": round(B * N * args.steps / max(own_elapsed, 1e-9), 2)}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine_rec)
     assert torch.isfinite(out).all(), "non-finite mel output"
 
     frames = B_total * N * args.steps
@@ -491,7 +523,9 @@ def main():
                    "global_batch": B_total, "per_gpu_batch": B, "seq_len": N, "nfe": nfe, "parallelism": f"utterance-sharded dp{world}",
                    "key_mask": "all-true (fixed-length utterances): CFM.sample selects the unmasked kernels, same values as the reference's masked path",
                    "residual_stream": "fp16 storage, fp32 arithmetic" if args.precision == "bf16" else "fp32"},
-        "distributed": {"world_size": dist.get_world_size() if world > 1 else 1, "backend": backend, "devices": devices},
+        "distributed": {"world_size": dist.get_world_size() if world > 1 else 1, "backend": backend, "devices": devices,
+                        # per rank: its own wall time, HIP-event time of sample() and of the all_gather per step, the collective alone
+                        "ranks": per_rank, "gather_payload_bytes": (bmax * N * 100 * 4) if world > 1 else 0},
     }
 
     if rank == 0:

@@ -23,6 +23,11 @@ enum GemmEpi {
                         // the fp32 residual add itself is fused into the next LayerNorm pass)
 };
 
+// LayerNorm fold (round 4; bf16 production mode of the DiT): the QKV / FF1 projections read the fp16 residual stream ITSELF as their A operand
+// against per-evaluation-time weights W' = fp16(W . diag(1 + scale)) on v_mfma_f32_16x16x32_f16 and apply the rest of
+//   LN(x) (1 + scale) + shift  ->  Linear      =      rstd[m] (acc[m][n] - mean[m] c1[n]) + c2[n],   c1 = rowsum W',  c2 = b + W . shift
+// in their epilogue (then RoPE / GELU as before); the row statistics come from the in-place residual epilogues of the launch in front
+// (out-projection / FF2: `stats_out` partial sums per 64-feature wave tile, folded by stats_finalize_kernel).  modules.py:301-317,610-641.
 struct GemmParams {
     const void* A;  // [M(or a_row_mod), K] activation dtype
     const void* W;  // DENSE: [N, K];  CONV31: [31][N][conv_win] (tap-major, zero outside the row's own group)
@@ -41,6 +46,8 @@ struct GemmParams {
     const float* gate;  // EPI_RESID: gate[b * gate_bstride + n] or null (=1)
     int gate_bstride;
     int rows_per_batch;      // sequence length N_seq: b(m) = m / rows_per_batch, position = m % rows_per_batch
+    int row0;                // tuned kernel: global row index of this launch's row 0 (a launch split into a whole-tile part and a ragged tail: the
+                             // tail's positions / batch indices continue where the first part ended; set by the launcher)
     const uint8_t* rowmask;  // [M] or null
     const uint8_t* rowbits;  // optional transposed form of rowmask for the tuned kernel's epilogue (launch_rowbits): byte [m/128][m%16], bit (m%128)/16
     const float* rope;       // [N_seq][32][2] (cos, sin)
@@ -48,6 +55,17 @@ struct GemmParams {
     int rope_heads;          // heads that receive RoPE
     // CONV31: channels per group (dim/16) and the padded input-channel window one 64-channel output tile reads
     int conv_cg, conv_win;
+    int site;        // block call site for the per-site tile-walk knobs: 0 = none, 1 = qkv, 2 = out-projection, 3 = FF1, 4 = FF2 (set by dit_eval; the
+                     // launcher no longer guesses it from N / K ratios, which misread ff_mult = 4 backbones and the long-skip linear)
+    // LayerNorm fold, consumer side (tuned kernel only; template flag LNF): A and W hold fp16, the accumulator starts from 0, `bias` is unused
+    const float* lnf_stats;  // [M][2] = (mean, rstd) of every token row of A, or null (no fold)
+    const float* lnf_c1;     // [N] row sums of W'
+    const float* lnf_c2;     // [N] bias + W . shift
+    // LayerNorm fold, producer side (EPI_RESID on the fp16 stream, tuned kernel only): per token row and 64-feature wave tile the partial sums
+    // (sum (h - pivot), sum (h - pivot)^2) over the fp16-ROUNDED values just stored: stats_out[(n / 64) * stats_ld + m] as float2, or null
+    float* stats_out;
+    int stats_ld;                // rows per 64-feature plane of stats_out
+    const float* stats_pivot;    // [M][2]: element 0 of row m is the pivot (the row's previous mean), or null (pivot 0)
     int tile_group;  // tuned kernel: token tiles per L2 patch (set by the launcher)
     int tile_reverse;  // tuned kernel: walk the tiles in the opposite order (producer / consumer cache experiments)
     int lean_epi;    // tuned kernel: whole tiles take the lean epilogue (set by the launcher; 0 = always the generic one)

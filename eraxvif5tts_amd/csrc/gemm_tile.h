@@ -44,6 +44,11 @@ __device__ __forceinline__ f32x4 epi_rope4(const f32x4& v, const f32x4& cs) {
 __device__ __forceinline__ f32x4 epi_axpy4(const f32x4& branch, const f32x4& gate, const f32x4& x) {
     return __builtin_elementwise_fma(branch, gate, x);
 }
+// LayerNorm fold: rstd (acc - mean c1) + c2, two fused multiply-adds per element (shared by the lean and the generic epilogue)
+__device__ __forceinline__ f32x4 epi_lnf4(const f32x4& acc, float mean, float rstd, const f32x4& c1, const f32x4& c2) {
+    const f32x4 nm{-mean, -mean, -mean, -mean}, rs{rstd, rstd, rstd, rstd};
+    return __builtin_elementwise_fma(rs, __builtin_elementwise_fma(nm, c1, acc), c2);
+}
 __device__ __forceinline__ float fast_mish(float x) {
     const float w = __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
     const float n = w * (w + 2.0f);

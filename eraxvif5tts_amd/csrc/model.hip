@@ -991,7 +991,7 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         F5_TRY(tap_t(p, tn + ".n1", p->hT, D, rows, D, st));
         g = gp_zero();
         g.A = p->hT; g.lda = D; g.W = b.w_qkv; g.ldw = D; g.M = rows; g.N = 3 * inner; g.K = D;
-        g.bias = b.b_qkv; g.out_t = p->qkv; g.ldo = 3 * inner; g.rows_per_batch = N;
+        g.bias = b.b_qkv; g.out_t = p->qkv; g.ldo = 3 * inner; g.rows_per_batch = N; g.site = 1;
         g.rope = rg ? p->rope_exp : p->rope; g.rope_inner = inner; g.rope_heads = m->rope_heads;  // (ragged: row r of a half -> its position in its utterance)
         // Tile quantisation at small batches: the fused projection has 12 feature tiles per token tile; when the q|k part alone (8 tiles
         // per token tile) fills the CUs a whole number of times but q|k|v does not (M = 8192, 4 utterances x 1024 frames x CFG: 256 + 128
@@ -1050,7 +1050,7 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         g = gp_zero();
         g.A = p->cT; g.lda = inner; g.W = b.w_o; g.ldw = inner; g.M = rows; g.N = D; g.K = inner;
         g.bias = b.b_o; g.out_t = defer ? p->yA : p->yT; g.ldo = D; g.gate = ml + 2 * D; g.gate_bstride = mod_bstride; g.rows_per_batch = N;
-        g.rowmask = mask;
+        g.rowmask = mask; g.site = 2;
         g.rowbits = (mask && mask == p->rowbits_src) ? p->rowbits : nullptr;
         if (rmw) {
             g.out_t = nullptr;
@@ -1069,12 +1069,12 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         }));
         g = gp_zero();
         g.A = p->hT; g.lda = D; g.W = b.w_ff1; g.ldw = D; g.M = rows; g.N = ff; g.K = D;
-        g.bias = b.b_ff1; g.act = ACT_GELU_TANH; g.out_t = p->ffh; g.ldo = ff;
+        g.bias = b.b_ff1; g.act = ACT_GELU_TANH; g.out_t = p->ffh; g.ldo = ff; g.site = 3;
         F5_TRY(timed(p, F5_SITE_FF1, st, [&] { return run_gemm(p, g, GEMM_DENSE, EPI_STORE_T, st); }));
         // y = gate_mlp * ff(n2)  (modules.py:639)
         g = gp_zero();
         g.A = p->ffh; g.lda = ff; g.W = b.w_ff2; g.ldw = ff; g.M = rows; g.N = D; g.K = ff;
-        g.bias = b.b_ff2; g.out_t = p->yT; g.ldo = D; g.gate = ml + 5 * D; g.gate_bstride = mod_bstride; g.rows_per_batch = N;
+        g.bias = b.b_ff2; g.out_t = p->yT; g.ldo = D; g.gate = ml + 5 * D; g.gate_bstride = mod_bstride; g.rows_per_batch = N; g.site = 4;
         if (rmw) {
             g.out_t = nullptr;
             g.out_f = reinterpret_cast<float*>(p->xres16);

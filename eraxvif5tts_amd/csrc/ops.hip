@@ -237,6 +237,7 @@ extern "C" int f5_bench_gemm_site(int kernel, int site, int rows, int seq, int d
         GemmParams g;
         memset(&g, 0, sizeof(g));
         g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = rows; g.N = N; g.K = K; g.bias = bias; g.rows_per_batch = seq;
+        g.site = N == 3 * K ? 1 : (N == K ? 2 : (N == 2 * K ? 3 : (K == 2 * N ? 4 : 0)));  // (this bench entry times the ff_mult = 2 DiT call sites)
         if (epi == EPI_ROPE_T) { g.out_t = out; g.ldo = N; g.rope = rope; g.rope_inner = inner; g.rope_heads = 1; }
         if (epi == EPI_STORE_T) { g.out_t = out; g.ldo = N; g.act = ACT_GELU_TANH; }
         if (epi == EPI_GATE_T) { g.out_t = out; g.ldo = N; g.gate = gate; g.gate_bstride = 0; }
@@ -362,6 +363,7 @@ extern "C" int f5_bench_mfma_rate(int random_operands, float* tflops, f5_stream_
 extern int g_sync_evals, g_attn_persist, g_attn_stagger, g_resid_rmw;
 extern int g_conv31_tok;
 extern int g_gemm_bm128, g_gemm_tile, g_gemm_group_sites, g_gemm_reverse_sites;
+extern int g_gemm_split_tail;
 extern int g_gemm_variant, g_gemm_group, g_gemm_persist_grid, g_gemm_persist, g_gemm_lean, g_ln_defer, g_ln_wide, g_ln_rows, g_ln_rows_min, g_w_prefetch, g_res_f16, g_conv31, g_attn_variant, g_vocos_fft;
 int g_tuning_epoch = 0;
 extern unsigned long long* g_attn_stamp_buf;
@@ -467,6 +469,10 @@ extern "C" int f5_tuning_set(const char* key, int value) {
     }
     if (strcmp(key, "gemm_lean") == 0) {
         g_gemm_lean = value != 0;
+        return 0;
+    }
+    if (strcmp(key, "gemm_split_tail") == 0) {
+        g_gemm_split_tail = value != 0;
         return 0;
     }
     if (strcmp(key, "gemm_persist") == 0) {

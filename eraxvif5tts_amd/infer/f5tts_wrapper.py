@@ -252,7 +252,12 @@ class F5TTSWrapper:
                                                      cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef, return_trajectory=False)
                 mels.append(generated)
         if n_streams > 1:
-            transformer.finish_pending()  # synchronises every chunk stream (and lets the library redo a chunk whose fp16 range guard fired)
+            transformer.finish_pending()  # reads every chunk's fp16 range-guard flag (and lets the library redo a chunk whose guard fired)
+            # finish_pending() synchronises a stream only when its plan has a guard to read (bf16 mode with fp16 storage); the vocoder below runs
+            # on the caller's stream, so that stream must be ordered behind EVERY chunk stream whatever the precision (round 4: the fp32 mode
+            # decoded mels that were still being written -- found by test_generate_end_to_end_matches_the_oracle_chain[fp32-False])
+            for st in streams:
+                main.wait_stream(st)
         with torch.inference_mode():
             for generated in mels:
                 if n_streams > 1:

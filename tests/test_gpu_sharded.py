@@ -86,6 +86,11 @@ def test_bench_gpus_flag_launches_the_ranks():
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["distributed"]["world_size"] == 2 and j["distributed"]["backend"] == "gloo"
     assert len(j["distributed"]["devices"]) == 2 and j["config"]["global_batch"] == 4 and j["config"]["per_gpu_batch"] == 2
     assert j["value"] > 0 and any(k["kernel"] == "attention" for k in j["roofline"]["kernels"])
+    # per-rank record: own wall time, HIP-event time of sample() and of the gather, the collective alone (separates batch efficiency, skew, gather)
+    ranks = j["distributed"]["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and all(r["utterances"] == 2 and r["sample_ms"] > 0 and r["gather_only_ms"] >= 0 and
+                                                       r["elapsed_s"] * 1e3 >= r["sample_ms"] for r in ranks)
+    assert j["distributed"]["gather_payload_bytes"] == 2 * 256 * 100 * 4
     # a WORLD_SIZE that contradicts --gpus is an error, not a silent single-GPU run
     env["WORLD_SIZE"] = "4"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=120)
