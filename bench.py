@@ -350,6 +350,35 @@ def extra_workloads(args, dev, model, cfm):
                                 "config": f"4 utterances of {durs} frames over one 300-frame prompt, NFE={nfe} CFG={args.cfg:g} sway=-1, bf16, eager launches"}
     del ref, got, cond1, texts, y0s
     torch.cuda.empty_cache()
+    # Batched inference over length buckets (the reference's production-shaped multi-utterance caller: eval/utils_eval.py:72-204 builds
+    # frame-budgeted buckets, eval_infer_batch.py:160-196 samples each as ONE padded + masked batch).  Synthetic set with a stated length
+    # distribution (no dataset offline): 48 utterances, total length uniform in 3..20 s, prompt 2..6 s; buckets of >= 6 000 frames.  Padded
+    # form (the reference's) against the ragged sampler (no padding, no key mask, a prompt per utterance); third pass of each (the second
+    # pass of a shape captures its hipGraph, the third replays it).
+    from eraxvif5tts_amd.eval import prompts as P
+    meta = P.synthetic_metainfo(48, seed=1, min_secs=3.0, max_secs=20.0)
+    buckets = P.get_inference_prompt(meta, tokenizer="char", infer_batch_size=6000, num_buckets=40, min_secs=3, max_secs=40, device=dev)
+    frames = sum(sum(b[4]) for b in buckets)
+    padded_rows = sum(len(b[4]) * max(b[4]) for b in buckets)
+    bkw = dict(nfe_step=nfe, cfg_strength=args.cfg, sway_sampling_coef=-1.0, seed=0)
+    times = {}
+    for mode in ("padded", "ragged"):
+        for _pass in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_out = sum(1 for _ in P.infer_prompts(cfm, buckets, mode=mode, **bkw))
+            torch.cuda.synchronize()
+            times[mode] = time.perf_counter() - t0
+        assert n_out == len(meta)
+    out["bucketed_eval"] = {"value": round(frames / times["ragged"], 2), "unit": "mel-frames/s", "ms_per_step": round(times["ragged"] * 1e3, 3),
+                            "padded_value": round(frames / times["padded"], 2), "padded_ms": round(times["padded"] * 1e3, 3),
+                            "speedup_vs_padded": round(times["padded"] / times["ragged"], 3), "utterances": len(meta), "buckets": len(buckets),
+                            "frames": int(frames), "padded_rows": int(padded_rows),
+                            "config": f"48 synthetic utterances, total length U(3, 20) s, prompt U(2, 6) s, {len(buckets)} buckets of >= 6000 frames "
+                                      f"(utils_eval.get_inference_prompt), NFE={nfe} CFG={args.cfg:g} sway=-1, bf16; value = ragged sampler, "
+                                      "padded_value = the reference's padded + masked batches; hipGraph replay of recurring bucket shapes"}
+    del buckets, meta
+    torch.cuda.empty_cache()
     v = bench_vocos(args, dev, T=683, B=32, steps=20, warmup=3)
     out["C5"] = {"value": v["value"], "unit": v["unit"], "ms_per_step": v["ms_per_step"], "rtf": v["rtf"], "config": v["config"]["workload"],
                  "head_gbs": v["roofline"]["achieved"], "head_frac": v["roofline"]["frac"],

@@ -70,7 +70,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
         extra = EXTRA_FLAGS.get(src, [])
         h = hdr.copy()
         with open(os.path.join(CSRC, src), "rb") as fh:
-            h.update(fh.read())
+            text = fh.read()
+        h.update(text)
+        for line in text.decode("utf-8", "replace").splitlines():  # a .hip that includes another .hip (second translation unit of one template)
+            if line.startswith('#include "') and line.rstrip().endswith('.hip"'):
+                with open(os.path.join(CSRC, line.split('"')[1]), "rb") as fh:
+                    h.update(fh.read())
         h.update(" ".join(FLAGS + extra).encode())
         ostamp = obj + ".digest"
         if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read() == h.hexdigest():

@@ -175,6 +175,7 @@ int launch_gemm(const GemmParams& p, int precision, int mode, int epi, int kerne
             return f5_fail(F5_EINVAL, "gemm(conv31): N must be a multiple of 64, M a whole number of sequences, group size a multiple of 8");
     }
     if ((epi == EPI_RESID || epi == EPI_ROPE_T || epi == EPI_GATE_T) && p.rows_per_batch <= 0) return f5_fail(F5_EINVAL, "gemm: rows_per_batch missing");
+    if ((p.lnf_stats || p.stats_out) && kernel_kind != 1) return f5_fail(F5_ESTATE, "gemm: the LayerNorm fold exists in the tuned kernel only");
     if (kernel_kind == 1) {
         if (!gemm_fast_supported(p, precision, mode, epi)) return f5_fail(F5_EINVAL, "gemm: tuned kernel does not support this problem");
         return launch_gemm_fast(p, mode, epi, stream);

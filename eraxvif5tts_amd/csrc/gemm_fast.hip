@@ -23,7 +23,13 @@
 //   * rows >= M / features >= N are clamped on load and dropped in the epilogue, so no padding contract on the caller.
 #include "gemm_tile.h"
 
+// This file is compiled as TWO translation units (build time): gemm_fast.hip itself holds every instantiation without the LayerNorm fold,
+// gemm_fast_lnf.hip (#define F5_LNF_TU + #include of this file) the LNF ones behind launch_gemm_fast_lnf().
+#ifdef F5_LNF_TU
+static __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];  // (GEMM_CONV31 only; never read in the LNF instantiations)
+#else
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];  // zero-initialised
+#endif
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -172,31 +178,28 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
     bool wide_ok;
     int nwide;
     [[maybe_unused]] unsigned keepbits = 0xffu;  // lean epilogue: bit j = row (j * 16 + fr) of this wave's token rows is kept
-    // LNF: the column constants of this wave's 64 features (c1 = row sums of W', c2 = bias + W . shift) are staged in LDS -- 2 x 256 bytes by
-    // two dword LDS-DMA instructions into the start of the wave's OWN activation-piece area of a ring slot that holds no live stage -- and read
-    // back per feature tile inside the epilogue: 32 registers fewer than holding them (the QKV + RoPE build spilled with them in registers).
-    // Only this wave writes that area again (its next DMA piece, behind its own reads in program order), so no barrier is involved.
+    // LNF: the epilogue operands of this wave -- the column constants of its 64 features (c1 = row sums of W', c2 = bias + W . shift: 2 x 256
+    // bytes, two dword LDS-DMA instructions) and (mean, rstd) of its WM token rows (8 bytes a row, one dwordx4 LDS-DMA instruction) -- are
+    // staged in a 2-KiB LDS area of the wave's own and read back inside the epilogue: 48 registers fewer than holding them (the QKV + RoPE
+    // build spilled with them in registers).  Persistent schedule: the area is the start of the wave's OWN activation pieces in the ring slot
+    // the DMA front writes next (it holds no live stage; only this wave writes there again, behind its own reads in program order, so no
+    // barrier is involved).  Other schedules: the ring is dead after the main loop (one barrier), the area is smem + wave * 2048.
     [[maybe_unused]] char* lnf_lds = nullptr;
-    [[maybe_unused]] f32x2 lst[WM / 16];  // LNF: (mean, rstd) of this lane's token rows
-    [[maybe_unused]] auto stage_lnf_cols = [&](int tn0, int slot) {
-        lnf_lds = smem + slot * STAGE + wave * APW * 1024;
+    [[maybe_unused]] auto stage_lnf = [&](int tm0, int tn0, char* area) {
+        lnf_lds = area;
         int n = tn0 + wn * WN + lane;
         n = n < p.N ? n : 0;
         __builtin_amdgcn_global_load_lds((gptr_t)(p.lnf_c1 + n), (lptr_t)lnf_lds, 4, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr_t)(p.lnf_c2 + n), (lptr_t)(lnf_lds + 256), 4, 0, 0);
+        // rows tm0 + wm * WM .. + WM - 1: lane l fetches rows 2l, 2l + 1 (the statistics buffer is padded, rows >= M are never used)
+        if (WM >= 128 || lane < WM / 2)
+            __builtin_amdgcn_global_load_lds((gptr_t)(p.lnf_stats + ((size_t)(tm0 + wm * WM) + 2 * lane) * 2), (lptr_t)(lnf_lds + 512), 16, 0, 0);
     };
-    [[maybe_unused]] auto lnf_apply = [&](const f32x4& a, int i, const f32x2& st) {
+    [[maybe_unused]] auto lnf_apply = [&](const f32x4& a, int i, int j) {
         const f32x4 c1 = *reinterpret_cast<const f32x4*>(lnf_lds + (i * 16 + 4 * fq) * 4);
         const f32x4 c2 = *reinterpret_cast<const f32x4*>(lnf_lds + 256 + (i * 16 + 4 * fq) * 4);
+        const f32x2 st = *reinterpret_cast<const f32x2*>(lnf_lds + 512 + (j * 16 + fr) * 8);
         return epi_lnf4(a, st[0], st[1], c1, c2);
-    };
-    [[maybe_unused]] auto load_lnf_rows = [&](int tm0) {
-#pragma unroll
-        for (int j = 0; j < WM / 16; ++j) {
-            int m = tm0 + wm * WM + j * 16 + fr;
-            m = m < p.M ? m : p.M - 1;
-            lst[j] = *reinterpret_cast<const f32x2*>(p.lnf_stats + (size_t)m * 2);
-        }
     };
     auto prep_epilogue = [&]() {
         if constexpr (EPI == EPI_GATE_T || EPI == EPI_RESID) {
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
             static_for<NI>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 f32x4 v = acc[i][j0 + jj];  // bias: see init_acc
-                if constexpr (LNF) v = lnf_apply(v, i, lst[j0 + jj]);
+                if constexpr (LNF) v = lnf_apply(v, i, j0 + jj);
                 if constexpr (EPI == EPI_STORE_T || EPI == EPI_STORE_F32 || EPI == EPI_GATE_T || EPI == EPI_RESID) {
                     if (p.act == ACT_GELU_TANH) {
                         v = epi_gelu_tanh4(v);
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 f32x4 v = acc[i][j];
-                if constexpr (LNF) v = lnf_apply(v, i, lst[j]);
+                if constexpr (LNF) v = lnf_apply(v, i, j);
                 if constexpr (ACT == ACT_GELU_TANH) {
                     v = epi_gelu_tanh4(v);
                 } else if constexpr (ACT == ACT_MISH) {
@@ -640,9 +643,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
         return ok;
     };
     auto epilogue = [&]() {
-        if constexpr (LNF && !P30) {  // (every stage of the ring has been consumed: slot nk % NSTAGE held stage nk - NSTAGE)
-            stage_lnf_cols(n0, nk % NSTAGE);
-            load_lnf_rows(m0);
+        if constexpr (LNF && !P30) {  // the ring is dead once every wave has retired its last fragment reads
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stage_lnf(m0, n0, smem + wave * 2048);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if constexpr (P30 && EPI == EPI_RESID) {  // (the launcher guarantees whole tiles, the fp16 stream and lean operand forms)
@@ -775,18 +779,13 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
                 f32x4 bn[NI];
                 if (t + 1 < my_tiles) tile_mn(blockIdx.x + (t + 1) * G, nm0, nn0);
                 if constexpr (LNF) {  // no bias: THIS tile's column constants and row statistics travel across the barrier instead
-                    stage_lnf_cols(n0, slot_i);  // the DMA front's next slot holds no live stage (see the ring invariants above)
-                    load_lnf_rows(m0);
+                    stage_lnf(m0, n0, smem + slot_i * STAGE + wave * APW * 1024);  // the DMA front's next slot holds no live stage
 #pragma unroll
                     for (int i = 0; i < NI; ++i) bn[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                 } else {
                     load_bias(nn0, bn);  // in flight across the re-synchronising barrier
                 }
                 if (!late) __builtin_amdgcn_s_barrier();  // same barrier count for both groups; both now store together
-                if constexpr (LNF) {
-#pragma unroll
-                    for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(lst[j]));
-                }
 #pragma unroll
                 for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(bn[i]));  // the wait for the bias sits here: only loads are in flight
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and every K-step fetched ahead has landed (see the main loop)
@@ -852,12 +851,19 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
     clk_end();
 }
 
+#ifdef F5_LNF_TU
+extern unsigned long long* g_gemm_clk_buf;
+extern int g_gemm_variant, g_gemm_group, g_gemm_persist_grid, g_gemm_persist, g_gemm_reverse_sites, g_gemm_group_sites, g_gemm_tile, g_gemm_bm128, g_gemm_lean,
+    g_gemm_split_tail;
+int gemm_persist_grid();
+static int persist_grid() { return gemm_persist_grid(); }
+#else
 unsigned long long* g_gemm_clk_buf = nullptr;  // diagnostic (f5_debug_gemm_clock)
 int g_gemm_variant = 1;  // tuning knob (f5_tuning_set("gemm_variant", v)): 0 = plain ring everywhere, 1 = staggered wave groups (+ persistent grid)
 int g_gemm_group = 0;    // tuning knob ("gemm_group"): token tiles per L2 patch (0 = by shape, 1 = feature-tile-fastest order)
 int g_gemm_persist_grid = 0;  // tuning knob ("gemm_persist_grid"): workgroups of the persistent kernel (0 = one per CU of the device)
 int g_gemm_persist = 1;       // tuning knob ("gemm_persist"): 1 = whole-tile block linears run on the persistent grid
-static int persist_grid() {
+int gemm_persist_grid() {
     if (g_gemm_persist_grid > 0) return g_gemm_persist_grid;
     static int cus = 0;
     if (cus == 0) {
@@ -878,6 +884,9 @@ int g_gemm_tile = 0;   // diagnostic knob ("gemm_tile"): bm * 1000 + bn forces t
 int g_gemm_bm128 = 1;  // tuning knob ("gemm_bm128"): 128-row token tiles when the 256-row ones leave CUs without a workgroup (single-utterance launches)
 int g_gemm_lean = 1;   // tuning knob ("gemm_lean"): 1 = lean epilogue on whole tiles, 0 = generic epilogue everywhere
 int g_gemm_split_tail = 1;  // tuning knob ("gemm_split_tail"): 1 = M % 256 != 0 launches run as persistent whole tiles + a tail launch, 0 = one non-persistent launch
+
+static int persist_grid() { return gemm_persist_grid(); }
+#endif
 
 template <int BN, int WM, int MODE, int EPI, bool LNF = false> static int launch_fast(const GemmParams& p0, hipStream_t stream) {
     GemmParams p = p0;
@@ -953,6 +962,8 @@ template <int BN, int WM, int MODE, int EPI, bool LNF = false> static int launch
     return 0;
 }
 
+#ifndef F5_LNF_TU
+int launch_gemm_fast_lnf(const GemmParams& p, int epi, int bm, int bn, hipStream_t stream);  // gemm_fast_lnf.hip
 bool gemm_fast_supported(const GemmParams& p, int precision, int mode, int epi) {
     if (precision != F5_PREC_BF16 || p.M <= 0 || p.N <= 0) return false;
     if (p.lda & 7) return false;
@@ -1010,17 +1021,7 @@ int launch_gemm_fast(const GemmParams& p, int mode, int epi, hipStream_t stream)
     }
     if (p.lnf_stats) {  // LayerNorm fold: fp16 operands, statistics + column constants in the epilogue (QKV + RoPE, FF1 + GELU)
         if (!p.lnf_c1 || !p.lnf_c2 || (epi != EPI_STORE_T && epi != EPI_ROPE_T)) return f5_fail(F5_EINVAL, "gemm_fast: LayerNorm fold needs c1, c2 and a store / RoPE epilogue");
-#define F5_FAST_LNF(E)                                                                           \
-    if (epi == E) {                                                                              \
-        if (bm == 128 && bn == 128) return launch_fast<128, 32, GEMM_DENSE, E, true>(p, stream); \
-        if (bm == 128) return launch_fast<64, 16, GEMM_DENSE, E, true>(p, stream);               \
-        if (bn == 256) return launch_fast<256, 128, GEMM_DENSE, E, true>(p, stream);             \
-        if (bn == 128) return launch_fast<128, 64, GEMM_DENSE, E, true>(p, stream);              \
-        return launch_fast<64, 32, GEMM_DENSE, E, true>(p, stream);                              \
-    }
-        F5_FAST_LNF(EPI_STORE_T)
-        F5_FAST_LNF(EPI_ROPE_T)
-#undef F5_FAST_LNF
+        return launch_gemm_fast_lnf(p, epi, bm, bn, stream);
     }
     if (p.stats_out && (epi != EPI_RESID || !p.add2_f16 || p.N % 64 != 0 || p.stats_ld < p.M))
         return f5_fail(F5_EINVAL, "gemm_fast: row statistics need the in-place fp16 residual epilogue and N % 64 == 0");
@@ -1042,3 +1043,19 @@ int launch_gemm_fast(const GemmParams& p, int mode, int epi, hipStream_t stream)
 #undef F5_FAST_CASE
     return f5_fail(F5_EINVAL, "gemm_fast: unsupported epilogue %d", epi);
 }
+#else  // F5_LNF_TU
+int launch_gemm_fast_lnf(const GemmParams& p, int epi, int bm, int bn, hipStream_t stream) {
+#define F5_FAST_LNF(E)                                                                           \
+    if (epi == E) {                                                                              \
+        if (bm == 128 && bn == 128) return launch_fast<128, 32, GEMM_DENSE, E, true>(p, stream); \
+        if (bm == 128) return launch_fast<64, 16, GEMM_DENSE, E, true>(p, stream);               \
+        if (bn == 256) return launch_fast<256, 128, GEMM_DENSE, E, true>(p, stream);             \
+        if (bn == 128) return launch_fast<128, 64, GEMM_DENSE, E, true>(p, stream);              \
+        return launch_fast<64, 32, GEMM_DENSE, E, true>(p, stream);                              \
+    }
+    F5_FAST_LNF(EPI_STORE_T)
+    F5_FAST_LNF(EPI_ROPE_T)
+#undef F5_FAST_LNF
+    return f5_fail(F5_EINVAL, "gemm_fast: LayerNorm fold supports the store and RoPE epilogues");
+}
+#endif

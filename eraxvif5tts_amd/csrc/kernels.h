@@ -106,3 +106,13 @@ int launch_vocos_spectrum(int precision_out, const float* head, int ldh, int row
 int launch_vocos_ifft1024(const float* head, int ldh, int rows, const float* wscaled, const float* twiddle, float* frames, hipStream_t stream);
 // overlap-add of windowed frames [B*T, n_fft] (hop), divide by the window-square envelope, trim n_fft/2 each side
 int launch_vocos_ola(const float* frames, int B, int T, int n_fft, int hop, const float* wsq /*[n_fft]*/, float* wave, hipStream_t stream);
+
+// ---- LayerNorm fold (lnfold.hip; gemm.h)
+// per-evaluation-time projection weights W' = fp16(W (1 + scale)) and column constants c1 = rowsum W', c2 = b + W . shift for `evals` times x `depth`
+// blocks x R rows (R = 3 * inner + ff; rows < qkv_rows take the attention norm's shift / scale, the others the FF norm's)
+int launch_fold_weights(const float* W, const float* bias, const float* mod, int modrow, int evals, int depth, int R, int qkv_rows, int D, void* Wt,
+                        float* c1, float* c2, hipStream_t stream);
+// partial row sums of an in-place residual GEMM ([ncols][ld] float2 planes) -> stats[row] = (mean, rstd); also the fp16 range guard of the stream
+int launch_stats_finalize(const float* partial, int ld, int ncols, int rows, int D, const float* pivot, float* stats, unsigned* sat, int sat_tag,
+                          hipStream_t stream);
+

@@ -1,0 +1,116 @@
+// lnfold.hip -- the two small kernels of the LayerNorm fold (gemm.h):
+//
+//   fold_weights_kernel     once per time grid: for every evaluation time e and DiT block l the per-time weights of the two projections that
+//                           follow an AdaLN LayerNorm (modules.py:301-317: attn_norm -> to_q|to_k|to_v;  modules.py:637-638: ff_norm -> ff.0.0)
+//                               W'[e][l][n][k] = fp16( W[l][n][k] * (1 + scale[e][l][k]) )
+//                               c1[e][l][n]    = sum_k float(W'[e][l][n][k])            (of the ROUNDED values: what the MFMA multiplies)
+//                               c2[e][l][n]    = b[l][n] + sum_k W[l][n][k] * shift[e][l][k]
+//                           so that  Linear(LN(x) (1 + scale) + shift) = rstd (x . W'^T - mean c1) + c2  with x the fp16 residual stream itself.
+//   stats_finalize_kernel   after every in-place residual GEMM: the per-wave-tile partial sums its epilogue wrote (sum (h - pivot), sum (h - pivot)^2
+//                           per token row and 64-feature tile) -> (mean, rstd) per row, eps = 1e-6 (modules.py:308,624), and the fp16 range guard
+//                           of the stream (the LayerNorm passes that carried it are gone): a row whose sum of squares reaches 65504^2 -- any
+//                           element stored at the saturation value does that -- or is not a number raises the plan's flag words.
+#include "common.h"
+#include "kernels.h"
+
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float wave_sum_fixed(float v) {  // xor butterfly: every lane ends with the same total, fixed order
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// grid (ceil(R_total / 4), evals), 256 threads = 4 output rows.  R = rows per block = 3 * inner + ff; row r of block l: r < 3 * inner belongs to the
+// attention norm (shift_msa at mod + l * 6D, scale_msa at + D), else to the FF norm (shift_mlp at + 3D, scale_mlp at + 4D)  (modules.py:312).
+__global__ __launch_bounds__(256) void fold_weights_kernel(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ mod,
+                                                           int modrow, int depth, int R, int qkv_rows, int D, _Float16* __restrict__ Wt,
+                                                           float* __restrict__ c1, float* __restrict__ c2) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);  // over depth * R
+    const int e = blockIdx.y;
+    if (row >= depth * R) return;
+    const int l = row / R, r = row - l * R;
+    const float* ml = mod + (size_t)e * modrow + (size_t)l * 6 * D;
+    const float* shift = ml + (r < qkv_rows ? 0 : 3 * D);
+    const float* scale = shift + D;
+    const float* w = W + (size_t)row * D;
+    _Float16* wo = Wt + ((size_t)e * depth * R + row) * D;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
+        f16x4_t h;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            h[k] = (_Float16)(wv[k] * (1.0f + sc[k]));
+            s1 += (float)h[k];
+            s2 = __builtin_fmaf(wv[k], sh[k], s2);
+        }
+        *reinterpret_cast<f16x4_t*>(wo + c) = h;
+    }
+    s1 = wave_sum_fixed(s1);
+    s2 = wave_sum_fixed(s2);
+    if (lane == 0) {
+        c1[(size_t)e * depth * R + row] = s1;
+        c2[(size_t)e * depth * R + row] = bias[row] + s2;
+    }
+}
+
+int launch_fold_weights(const float* W, const float* bias, const float* mod, int modrow, int evals, int depth, int R, int qkv_rows, int D, void* Wt,
+                        float* c1, float* c2, hipStream_t stream) {
+    if (evals <= 0 || depth <= 0 || R <= 0 || D % 4 != 0) return f5_fail(F5_EINVAL, "fold_weights: bad shape");
+    hipLaunchKernelGGL(fold_weights_kernel, dim3((unsigned)((depth * R + 3) / 4), (unsigned)evals), dim3(256), 0, stream, W, bias, mod, modrow, depth, R,
+                       qkv_rows, D, (_Float16*)Wt, c1, c2);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+// one thread per token row: partial[c * ld + row] = (s1, s2) of feature tile c (ncols = D / 64), added in the order c = 0, 1, ... (fixed)
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const f32x2_t* __restrict__ partial, int ld, int ncols, int rows, int D,
+                                                             const float* pivot /* [rows][2] or null; may alias `stats` */, float* stats, unsigned* sat,
+                                                             int sat_tag) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    bool bad = false;
+    float sumsq = 0.f;
+    if (row < rows) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = 0; c < ncols; ++c) {
+            const f32x2_t v = partial[(size_t)c * ld + row];
+            s1 += v[0];
+            s2 += v[1];
+        }
+        const float pv = pivot ? pivot[(size_t)row * 2] : 0.0f;
+        const float inv = 1.0f / (float)D;
+        const float md = s1 * inv;  // mean - pivot
+        float var = __builtin_fmaf(-md, md, s2 * inv);
+        var = var > 0.f ? var : 0.f;
+        stats[(size_t)row * 2] = pv + md;
+        stats[(size_t)row * 2 + 1] = 1.0f / sqrtf(var + 1e-6f);
+        // sum of squares of the stored elements themselves (not about the pivot): s2 + 2 pv s1 + D pv^2
+        sumsq = __builtin_fmaf(pv, __builtin_fmaf(2.0f, s1, (float)D * pv), s2);
+        bad = !(sumsq < 65504.0f * 65504.0f);
+    }
+    if (sat && __builtin_amdgcn_ballot_w64(bad) != 0ull) {  // rare: same flag words as res_range_guard (elementwise.hip)
+        if (bad) {
+            const float bound = sqrtf(sumsq);  // an upper bound of the row's largest |element|
+            if (bound == bound && bound < 3.0e38f) atomicMax(sat + 1, __float_as_uint(bound));
+            if (!(sumsq == sumsq)) __hip_atomic_store(sat + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicOr(sat + 3, 1u << (sat_tag & 15));
+            atomicOr(sat + 4, 1u << ((sat_tag >> 4) & 31));
+            atomicMax(sat + 5, 0x7fffffffu - (unsigned)row);
+        }
+    }
+}
+
+int launch_stats_finalize(const float* partial, int ld, int ncols, int rows, int D, const float* pivot, float* stats, unsigned* sat, int sat_tag,
+                          hipStream_t stream) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<const f32x2_t*>(partial), ld,
+                       ncols, rows, D, pivot, stats, sat, sat_tag);
+    F5_LAUNCH_CHECK();
+    return 0;
+}

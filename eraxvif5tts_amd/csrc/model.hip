@@ -38,6 +38,22 @@ struct TextBlockW {
     void *w1 = nullptr, *w2 = nullptr;
 };
 
+// per-evaluation-time weights of one time grid (lnfold.hip: fold_weights_kernel), shared by every plan of the model that samples on this grid
+struct FoldTable {
+    std::vector<float> tv;  // the evaluation times it was built for
+    DevArena arena;
+    void* Wt = nullptr;     // [evals][depth][R][D] fp16
+    float *c1 = nullptr, *c2 = nullptr;  // [evals][depth][R]
+    hipEvent_t ready = nullptr;          // recorded behind the build; a plan on another stream waits for it once
+    uint64_t id = 0;
+    int users = 0;          // plans holding it (their captured graphs bake its addresses)
+    ~FoldTable() {
+        if (ready) (void)hipEventDestroy(ready);
+    }
+};
+static const size_t F5_FOLD_TABLES = 2;
+static const int F5_FOLD_MAX_EVALS = 64;  // 64 evaluation times x 231 MB (F5TTS_Base) = 14.8 GB; longer grids run the unfolded path
+
 struct f5_model_s {
     f5_dit_config cfg;
     SlotMap slots;
@@ -61,7 +77,18 @@ struct f5_model_s {
     int in_td = 0;           // text columns of the input projection (text_dim; 0 for MMDiT, whose text is a stream of its own)
     int text_pos_rows = 4096;  // rows of the sinusoidal table added to the text embedding (dit.py:41; 1024 mmdit.py:37)
     float inv_freq[32];
+    // LayerNorm fold (gemm.h; bf16 DiT without qk_norm): fp32 masters of the two projections behind an AdaLN LayerNorm, [depth][R][D] with
+    // R = 3 * inner (fused q|k|v rows) + ff (ff.0.0 rows), their biases [depth][R], and the per-time-grid tables built from them
+    float *w_fold = nullptr, *b_fold = nullptr;
+    int fold_R = 0;
+    std::vector<FoldTable*> folds;  // at most F5_FOLD_TABLES time grids, oldest dropped first (never one a plan still points to)
+    uint64_t fold_seq = 0;
+    ~f5_model_s();
 };
+
+f5_model_s::~f5_model_s() {
+    for (FoldTable* t : folds) delete t;
+}
 
 extern int g_tuning_epoch;  // bumped by every f5_tuning_set: graphs captured under other knob values are dropped (ops.hip)
 
@@ -69,6 +96,8 @@ struct GraphEntry {
     int B, N, nt, steps, method, cfg_on, mask_on;
     float cfg;
     int epoch;
+    uint64_t fold_id = 0;  // the FoldTable whose addresses the capture baked (0 = none)
+    std::vector<int> rn;   // ragged sample(): the utterances' frame counts (empty: a uniform batch)
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
 };
@@ -120,6 +149,7 @@ struct f5_plan_s {
     unsigned* sat_host = nullptr;  // pinned
     int res_f16 = -1;              // plan option "residual_f16": -1 = the process-wide knob, 0 = fp32 storage, 1 = fp16 storage
     int sat_check = 1;             // plan option "residual_guard": 0 = never read the flag (f5_sample stays fully asynchronous)
+    int ragged_graph = 0;          // plan option "ragged_graph": f5_sample_ragged replays a hipGraph captured for this exact list of frame counts
     PendingSample pending;
     // UNetT (unett.py:185-253): the stream carries one time token per utterance in front of the frames
     float* xin_res = nullptr;          // input projection + hoisted embedding, before the time token is prepended [B*N, D]
@@ -142,6 +172,11 @@ struct f5_plan_s {
     unsigned sat_amax_bits = 0;    // what the last event saw: largest finite |element| (float bits) and whether a NaN was read
     bool sat_nan = false;
     unsigned sat_pass = 0, sat_blocks = 0, sat_row = 0;  // which passes / DiT blocks raised it, smallest offending token row
+    // LayerNorm fold: the time grid's table (model-owned, shared), row statistics (mean, rstd) [rows_cap + 256][2], partial sums
+    // [D / 64][rows_cap] float2 of the in-place residual epilogues
+    FoldTable* fold = nullptr;
+    float *lnf_stats = nullptr, *lnf_partial = nullptr;
+    int fold_eval = -1;  // evaluation index of the running net_eval (-1: no table row applies, e.g. f5_dit_forward's per-sample times)
     std::map<std::string, float*> taps;
     std::vector<float> mod_tv;  // evaluation times the AdaLN rows in `mod` were computed for (empty = stale); see f5_sample
     hipStream_t mod_stream = nullptr;  // ... and the stream they were computed on (a call on another stream recomputes them)
@@ -480,6 +515,10 @@ extern "C" int f5_model_finalize(f5_model_t m) {
     // transformer blocks: fused QKV weight [3*inner, D]
     m->blocks.resize(c.depth);
     const bool un = c.backbone == F5_BACKBONE_UNETT;
+    // LayerNorm fold: fp32 masters of the fused q|k|v and the first FF projection of every block, as the kernels see them (RoPE row order)
+    const bool fold = c.backbone == F5_BACKBONE_DIT && P == F5_PREC_BF16 && !c.qk_norm && !c.long_skip && D % 128 == 0;
+    const size_t foldR = 3 * inner + ff;
+    std::vector<float> fold_w(fold ? (size_t)c.depth * foldR * D : 0), fold_b(fold ? (size_t)c.depth * foldR : 0);
     for (int i = 0; i < c.depth; ++i) {
         const std::string p = (un ? "layers." : "transformer_blocks.") + std::to_string(i) + ".";
         const std::string pa = p + (un ? "2." : "attn."), pf = p + (un ? "4." : mm ? "ff_x." : "ff.");
@@ -510,6 +549,10 @@ extern "C" int f5_model_finalize(f5_model_t m) {
                         }
                     }
             }
+            if (fold && sfx.empty()) {
+                memcpy(&fold_w[(size_t)i * foldR * D], w.data(), w.size() * sizeof(float));
+                memcpy(&fold_b[(size_t)i * foldR], bias.data(), bias.size() * sizeof(float));
+            }
             F5_TRY(f5_upload_t(A, P, w.data(), w.size(), wdst));
             return f5_upload_f32(A, bias.data(), bias.size(), bdst);
         };
@@ -529,6 +572,10 @@ extern "C" int f5_model_finalize(f5_model_t m) {
         F5_TRY(f5_upload_f32(A, H(m, pa + "to_out.0.bias").data(), D, &b.b_o));
         F5_TRY(f5_upload_t(A, P, H(m, pf + "ff.0.0.weight").data(), ff * D, &b.w_ff1));
         F5_TRY(f5_upload_f32(A, H(m, pf + "ff.0.0.bias").data(), ff, &b.b_ff1));
+        if (fold) {
+            memcpy(&fold_w[((size_t)i * foldR + 3 * inner) * D], H(m, pf + "ff.0.0.weight").data(), ff * D * sizeof(float));
+            memcpy(&fold_b[(size_t)i * foldR + 3 * inner], H(m, pf + "ff.0.0.bias").data(), ff * sizeof(float));
+        }
         F5_TRY(f5_upload_t(A, P, H(m, pf + "ff.2.weight").data(), D * ff, &b.w_ff2));
         F5_TRY(f5_upload_f32(A, H(m, pf + "ff.2.bias").data(), D, &b.b_ff2));
         if (c.qk_norm) {  // (half-split rotary layout: the features of the rope heads were re-ordered above, their norm weights follow)
@@ -551,6 +598,12 @@ extern "C" int f5_model_finalize(f5_model_t m) {
             F5_TRY(f5_upload_f32(A, H(m, p + "3.g").data(), D, &b.g_ff));
             if (i >= c.depth / 2 && c.skip_connect == F5_SKIP_CONCAT) F5_TRY(f5_upload_t(A, P, H(m, p + "0.weight").data(), D * 2 * D, &b.w_skip));
         }
+    }
+    if (fold) {
+        F5_TRY(f5_upload_f32(A, fold_w.data(), fold_w.size(), &m->w_fold));
+        F5_TRY(f5_upload_f32(A, fold_b.data(), fold_b.size(), &m->b_fold));
+        m->fold_R = (int)foldR;
+        std::vector<float>().swap(fold_w);
     }
     if (un) F5_TRY(f5_upload_f32(A, H(m, "norm_out.g").data(), D, &m->g_out));
     if (c.long_skip) F5_TRY(f5_upload_t(A, P, H(m, "long_skip_connection.weight").data(), D * 2 * D, &m->w_lskip));
@@ -674,6 +727,10 @@ extern "C" int f5_plan_create(f5_model_t m, int max_batch, int max_seq, int max_
                 if ((rc = A.alloc_t(&sk, rows * D))) break;
             if (rc) break;
         }
+        if (m->w_fold) {  // LayerNorm fold: row statistics (padded: a wave's LDS-DMA fetches 128 rows at a time) and the epilogues' partial sums
+            if ((rc = A.alloc_t(&p->lnf_stats, (rows + 256) * 2))) break;
+            if ((rc = A.alloc_t(&p->lnf_partial, (D / 64) * rows * 2))) break;
+        }
         if ((rc = A.alloc_t(&p->sat_base, 1024))) break;  // the 8 flag words sit in the middle of a 4 KiB block of their own
         p->sat_flag = p->sat_base + 512;
         if (hipHostMalloc((void**)&p->sat_host, 32, hipHostMallocDefault) != hipSuccess) {
@@ -700,6 +757,7 @@ extern "C" int f5_plan_destroy(f5_plan_t p) {
         if (g.graph) (void)hipGraphDestroy(g.graph);
     }
     if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
+    if (p->fold) --p->fold->users;
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     if (p->sat_host) (void)hipHostFree(p->sat_host);
     delete p;
@@ -720,6 +778,8 @@ extern "C" int f5_plan_set_option(f5_plan_t p, const char* key, int value) {
         const int v = value < 0 ? -1 : (value != 0);
         rebake = p->res_f16 != v;
         p->res_f16 = v;
+    } else if (strcmp(key, "ragged_graph") == 0) {
+        p->ragged_graph = value != 0;  // (host-side only: which path the next f5_sample_ragged takes)
     } else if (strcmp(key, "residual_guard") == 0) {
         p->sat_check = value < 0 ? 0 : (value > 2 ? 2 : value);  // 0 off, 1 checked inside f5_sample, 2 deferred to f5_sample_finish (host-side only)
     } else {
@@ -747,6 +807,8 @@ extern "C" int f5_plan_get_option(f5_plan_t p, const char* key, int* value) {
         *value = plan_res_f16(p) ? 1 : 0;  // what the next evaluation will use
     else if (strcmp(key, "residual_guard") == 0)
         *value = p->sat_check;
+    else if (strcmp(key, "ragged_graph") == 0)
+        *value = p->ragged_graph;
     else if (strcmp(key, "residual_fallbacks") == 0)
         *value = p->fallbacks;
     else if (strcmp(key, "residual_guard_amax_bits") == 0)  // diagnostic: float bits of the largest finite |element| the last event saw
@@ -814,6 +876,7 @@ int g_w_prefetch = 16384;  // tuning knob ("w_prefetch"): LayerNorm passes prefe
 int g_res_f16 = 1;   // tuning knob ("residual_f16"): bf16 production mode keeps the residual stream in fp16 from the first block on (0 = fp32)
 int g_ln_defer = 1;  // tuning knob ("ln_defer"): write the residual stream once per DiT block (0 = after every LayerNorm pass)
 int g_resid_rmw = 1;  // tuning knob ("resid_rmw"): see dit_eval
+int g_ln_fold = 1;    // tuning knob ("ln_fold"): LayerNorm fold (dit_eval); 0 = the two LayerNorm passes per block of round 3
 int g_sync_evals = 0;  // diagnostic knob ("sync_evals"): an eager sample() synchronises the stream after every network evaluation, which bounds the
                        // number of dispatches in flight (profiles/r3_rocprof_pmc_sigsegv.md: rocprofv3 --pmc died under ~5 400 queued dispatches)
 
@@ -959,6 +1022,16 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
     // position-conv branch): 1 024 MiB of stream + branch traffic per block instead of 1 280, and the two passes shrink from 384 + 640 MiB to
     // 256 + 256.  Otherwise (fp32 stream, stage taps, per-sample time rows, knob "resid_rmw" = 0): store-only branches, adds fused into the passes.
     const bool rmw = r16 && mod_bstride == 0 && g_resid_rmw;
+    // LayerNorm fold (round 4; gemm.h, lnfold.hip): from the second LayerNorm of block 0 on, the two LayerNorm passes of a block are gone.  The
+    // in-place residual epilogues (out-projection, FF2) also write partial row sums of the values they store, stats_finalize_kernel turns them
+    // into (mean, rstd) per row -- and carries the fp16 range guard the passes carried -- and the QKV / FF1 projections read the fp16 stream
+    // itself against this evaluation time's W' = fp16(W (1 + scale)), applying rstd (acc - mean c1) + c2 in their epilogues.  Block 0's first
+    // pass stays (it folds the position-conv branch in), and so does the final AdaLN pass in front of proj_out.  Needs the in-place stream
+    // (rmw), the time grid's table (stage_time_grid) and the tuned kernel at all four call sites.
+    const FoldTable* ft = p->fold;
+    const bool lnf = rmw && g_ln_fold && ft && p->lnf_stats && p->fold_eval >= 0 && p->fold_eval < (int)ft->tv.size() && p->gemm_kernel != 0 &&
+                     (p->gemm_kernel == 1 || rows >= 512) && D % 64 == 0 && inner % 64 == 0 && ff % 64 == 0;
+    const size_t fR = (size_t)m->fold_R, frow0 = lnf ? ((size_t)p->fold_eval * c.depth) * fR : 0;
     for (int l = 0; l < c.depth; ++l) {
         const BlockW& b = m->blocks[l];
         const float* ml = modp + (size_t)l * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp (modules.py:312)
@@ -977,7 +1050,10 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         PrefetchSet pf1{{b.w_o, b.w_ff1, nullptr, nullptr}, {(unsigned)(D * inner * wes), (unsigned)(ff * D * wes), 0u, 0u}};
         PrefetchSet pf2{{b.w_ff2, l + 1 < c.depth ? m->blocks[l + 1].w_qkv : nullptr, nullptr, nullptr},
                         {(unsigned)(D * ff * wes), (unsigned)(3 * inner * D * wes), 0u, 0u}};
-        F5_TRY(timed(p, F5_SITE_LN1, st, [&] {
+        const bool lnf1 = lnf && l > 0;  // this block's first LayerNorm is folded into its QKV projection (statistics: the previous block's FF2)
+        const char* fW = lnf ? (const char*)ft->Wt + (frow0 + (size_t)l * fR) * D * 2 : nullptr;  // this block's W' rows: q|k|v, then ff.0.0
+        const float *fc1 = lnf ? ft->c1 + frow0 + (size_t)l * fR : nullptr, *fc2 = lnf ? ft->c2 + frow0 + (size_t)l * fR : nullptr;
+        if (!lnf1) F5_TRY(timed(p, F5_SITE_LN1, st, [&] {
             if (rmw)
                 return launch_layernorm_res(P, xin, 1, xout, 1, D, rows, D, l == 0 ? p->yT : nullptr, D, nullptr, 1, ml + D, ml, mod_bstride, N, 1, p->hT, D, st,
                                             wpf ? &pf1 : nullptr, sat, 1 | (l << 4));
@@ -993,6 +1069,10 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         g.A = p->hT; g.lda = D; g.W = b.w_qkv; g.ldw = D; g.M = rows; g.N = 3 * inner; g.K = D;
         g.bias = b.b_qkv; g.out_t = p->qkv; g.ldo = 3 * inner; g.rows_per_batch = N; g.site = 1;
         g.rope = rg ? p->rope_exp : p->rope; g.rope_inner = inner; g.rope_heads = m->rope_heads;  // (ragged: row r of a half -> its position in its utterance)
+        if (lnf1) {
+            g.A = p->xres16; g.W = fW; g.bias = nullptr;
+            g.lnf_stats = p->lnf_stats; g.lnf_c1 = fc1; g.lnf_c2 = fc2;
+        }
         // Tile quantisation at small batches: the fused projection has 12 feature tiles per token tile; when the q|k part alone (8 tiles
         // per token tile) fills the CUs a whole number of times but q|k|v does not (M = 8192, 4 utterances x 1024 frames x CFG: 256 + 128
         // tiles on 256 CUs, the second round half empty), v is projected by its own launch on 256 x 128 tiles: 70 -> 62 us per block.
@@ -1014,6 +1094,12 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
             gv.N = inner;
             gv.W = (const char*)b.w_qkv + (size_t)2 * inner * D * f5_elem_size(P);
             gv.bias = b.b_qkv + 2 * inner;
+            if (lnf1) {
+                gv.W = fW + (size_t)2 * inner * D * 2;
+                gv.bias = nullptr;
+                gv.lnf_c1 = fc1 + 2 * inner;
+                gv.lnf_c2 = fc2 + 2 * inner;
+            }
             gv.out_t = (char*)p->qkv + (size_t)2 * inner * f5_elem_size(P);
             gv.rope = nullptr;
             gv.rope_inner = gv.rope_heads = 0;
@@ -1058,9 +1144,15 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
             g.ldof = D;
             g.add2_f16 = 1;
         }
+        if (lnf) {  // partial row sums of the updated stream; pivot = the row's previous mean (none yet in block 0: the table is this evaluation's)
+            g.stats_out = p->lnf_partial; g.stats_ld = (int)p->rows_cap; g.stats_pivot = l > 0 ? p->lnf_stats : nullptr;
+        }
         F5_TRY(timed(p, F5_SITE_OUT, st, [&] { return run_gemm(p, g, GEMM_DENSE, rmw ? EPI_RESID : EPI_GATE_T, st); }));
         // x += y; n2 = LN(x) * (1 + scale_mlp) + shift_mlp
-        F5_TRY(timed(p, F5_SITE_LN2, st, [&] {
+        if (lnf) F5_TRY(timed(p, F5_SITE_LN2, st, [&] {
+            return launch_stats_finalize(p->lnf_partial, (int)p->rows_cap, D / 64, rows, D, l > 0 ? p->lnf_stats : nullptr, p->lnf_stats, sat, 2 | (l << 4), st);
+        }));
+        if (!lnf) F5_TRY(timed(p, F5_SITE_LN2, st, [&] {
             if (rmw)
                 return launch_layernorm_res(P, xin, 1, xout, 1, D, rows, D, nullptr, D, nullptr, 1, ml + 4 * D, ml + 3 * D, mod_bstride, N, 1, p->hT, D, st,
                                             wpf ? &pf2 : nullptr, sat, 2 | (l << 4));
@@ -1070,6 +1162,10 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
         g = gp_zero();
         g.A = p->hT; g.lda = D; g.W = b.w_ff1; g.ldw = D; g.M = rows; g.N = ff; g.K = D;
         g.bias = b.b_ff1; g.act = ACT_GELU_TANH; g.out_t = p->ffh; g.ldo = ff; g.site = 3;
+        if (lnf) {
+            g.A = p->xres16; g.W = fW + (size_t)3 * inner * D * 2; g.bias = nullptr;
+            g.lnf_stats = p->lnf_stats; g.lnf_c1 = fc1 + 3 * inner; g.lnf_c2 = fc2 + 3 * inner;
+        }
         F5_TRY(timed(p, F5_SITE_FF1, st, [&] { return run_gemm(p, g, GEMM_DENSE, EPI_STORE_T, st); }));
         // y = gate_mlp * ff(n2)  (modules.py:639)
         g = gp_zero();
@@ -1081,8 +1177,14 @@ static int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, cons
             g.ldof = D;
             g.add2_f16 = 1;
         }
+        const bool lnf_next = lnf && l + 1 < c.depth;  // (the final AdaLN pass reads the stream itself)
+        if (lnf_next) {
+            g.stats_out = p->lnf_partial; g.stats_ld = (int)p->rows_cap; g.stats_pivot = p->lnf_stats;
+        }
         F5_TRY(timed(p, F5_SITE_FF2, st, [&] { return run_gemm(p, g, GEMM_DENSE, rmw ? EPI_RESID : EPI_GATE_T, st); }));
-
+        if (lnf_next) F5_TRY(timed(p, F5_SITE_LN1, st, [&] {
+            return launch_stats_finalize(p->lnf_partial, (int)p->rows_cap, D / 64, rows, D, p->lnf_stats, p->lnf_stats, sat, 1 | ((l + 1) << 4), st);
+        }));
     }
     const float* mf = modp + (size_t)c.depth * 6 * D;  // final AdaLN: (scale, shift) (modules.py:333)
     // (no stage tap: the stream itself is not needed any more, so the last add is not written back)
@@ -1305,6 +1407,7 @@ static int net_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, int 
         return unett_eval(p, x, xrows, nb, N, p->temb + (size_t)time_row * m->cfg.dim, per_batch_rows ? m->cfg.dim : 0, mask, st);
     if (m->cfg.backbone == F5_BACKBONE_MMDIT)
         return mmdit_eval(p, x, xrows, nb, N, p->mod + (size_t)time_row * m->modrow, per_batch_rows ? m->modrow : 0, mask, st);
+    p->fold_eval = per_batch_rows ? -1 : time_row;  // (the fold table holds one set of weights per evaluation TIME of the staged grid)
     return dit_eval(p, x, xrows, nb, N, p->mod + (size_t)time_row * m->modrow, per_batch_rows ? m->modrow : 0, mask, st);
 }
 
@@ -1439,10 +1542,12 @@ static int run_sample_loop(f5_plan_s* p, const SampleArgs& a, int use_graph, hip
         }
         for (auto& g : p->graphs)
             if (g.B == a.B && g.N == a.N && g.nt == a.nt && g.steps == a.steps && g.method == a.method && g.cfg_on == a.cfg_on &&
-                g.mask_on == a.mask_on && g.cfg == a.cfg)
+                g.mask_on == a.mask_on && g.cfg == a.cfg && g.fold_id == (p->fold && g_ln_fold ? p->fold->id : 0) &&
+                g.rn == (p->rg ? p->rg->n : std::vector<int>()))
                 ge = &g;
         if (!ge) {
-            GraphEntry g{a.B, a.N, a.nt, a.steps, a.method, a.cfg_on, a.mask_on, a.cfg, g_tuning_epoch};
+            GraphEntry g{a.B, a.N, a.nt, a.steps, a.method, a.cfg_on, a.mask_on, a.cfg, g_tuning_epoch, (p->fold && g_ln_fold) ? p->fold->id : 0};
+            if (p->rg) g.rn = p->rg->n;
             if (!p->cap_stream) F5_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
             F5_HIP(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeRelaxed));
             int rc = sample_body(p, a, p->cap_stream);
@@ -1500,6 +1605,63 @@ static int finish_outputs(f5_plan_s* p, const SampleArgs& a, float* out, float* 
     return 0;
 }
 
+// LayerNorm fold: point the plan at the model's table for the evaluation times `tv` (p->mod holds their AdaLN rows, computed on `st`), building it
+// when no plan has sampled on this grid yet.  Never an error: without a table (knob off, grid too long, allocation refused) the unfolded path runs.
+static void drop_graphs(f5_plan_s* p);
+static int acquire_fold(f5_plan_s* p, const std::vector<float>& tv, hipStream_t st) {
+    f5_model_s* m = p->m;
+    const int nev = (int)tv.size();
+    FoldTable* want = nullptr;
+    if (m->w_fold && g_ln_fold && p->lnf_stats && nev > 0 && nev <= F5_FOLD_MAX_EVALS) {
+        for (FoldTable* t : m->folds)
+            if (t->tv == tv) want = t;
+        if (!want) {
+            for (size_t i = 0; i < m->folds.size() && m->folds.size() >= F5_FOLD_TABLES;) {  // oldest first, never one a plan still points to
+                if (m->folds[i]->users == 0 && m->folds[i] != p->fold) {
+                    (void)hipDeviceSynchronize();  // (launches of other streams may still read it)
+                    delete m->folds[i];
+                    m->folds.erase(m->folds.begin() + i);
+                } else {
+                    ++i;
+                }
+            }
+            const f5_dit_config& c = m->cfg;
+            const size_t n = (size_t)nev * c.depth * m->fold_R;
+            FoldTable* t = new FoldTable();
+            bool ok = t->arena.alloc(&t->Wt, n * c.dim * 2, false) == 0 && t->arena.alloc_t(&t->c1, n, false) == 0 && t->arena.alloc_t(&t->c2, n, false) == 0 &&
+                      hipEventCreateWithFlags(&t->ready, hipEventDisableTiming) == hipSuccess;
+            ok = ok && launch_fold_weights(m->w_fold, m->b_fold, p->mod, m->modrow, nev, c.depth, m->fold_R, 3 * m->inner, c.dim, t->Wt, t->c1, t->c2, st) == 0 &&
+                 hipEventRecord(t->ready, st) == hipSuccess;
+            if (!ok) {
+                (void)hipGetLastError();
+                delete t;
+            } else {
+                t->tv = tv;
+                t->id = ++m->fold_seq;
+                m->folds.push_back(t);
+                want = t;
+            }
+        } else if (want != p->fold) {
+            F5_HIP(hipStreamWaitEvent(st, want->ready, 0));  // built on another plan's stream
+        }
+    }
+    if (want != p->fold) {
+        if (p->fold) --p->fold->users;
+        p->fold = want;
+        if (want) ++want->users;
+        for (size_t i = 0; i < p->graphs.size();) {  // captures that baked another table's addresses
+            if (p->graphs[i].fold_id != (want ? want->id : 0)) {
+                (void)hipGraphExecDestroy(p->graphs[i].exec);
+                (void)hipGraphDestroy(p->graphs[i].graph);
+                p->graphs.erase(p->graphs.begin() + i);
+            } else {
+                ++i;
+            }
+        }
+    }
+    return 0;
+}
+
 // evaluation times / step coefficients of a fixed grid (fp32 op order of torchdiffeq's fixed-grid solvers) -> p->tvals / p->coefs, and the
 // AdaLN rows of every evaluation time -> p->mod (kept across calls with the same grid on the same stream)
 static int stage_time_grid(f5_plan_s* p, const float* tgrid_host, int steps, int ode_method, hipStream_t st) {
@@ -1528,6 +1690,7 @@ static int stage_time_grid(f5_plan_s* p, const float* tgrid_host, int steps, int
         p->mod_tv = tv;
         p->mod_stream = st;
     }
+    F5_TRY(acquire_fold(p, tv, st));
     return launch_set_floats(p->coefs, cf.data(), nev, st);
 }
 
@@ -1686,8 +1849,9 @@ extern "C" int f5_sample_ragged(f5_plan_t p, int B, const int32_t* frames_host, 
     SampleArgs a{B, T, nt, steps, ode_method, cfg_strength >= 1e-5f ? 1 : 0, 0, cfg_strength};  // cfm.py:167
     p->pending = PendingSample{};
     p->rg = &rg;
-    int rc = run_sample_loop(p, a, 0, st);
-    if (rc == 0 && plan_res_f16(p) && p->sat_check) rc = guard_check_and_fallback(p, a, 0, st);  // (always checked here: the call is eager anyway)
+    const int use_graph = p->ragged_graph;  // a bucket shape that recurs (batch inference over fixed buckets) replays its capture
+    int rc = run_sample_loop(p, a, use_graph, st);
+    if (rc == 0 && plan_res_f16(p) && p->sat_check) rc = guard_check_and_fallback(p, a, use_graph, st);  // (always checked inside the call)
     p->rg = nullptr;
     F5_TRY(rc);
     const float* xf = p->traj + (size_t)steps * T * mel;

@@ -228,22 +228,5 @@ def resample(waveform, orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99
     if waveform.is_cuda and lowpass_filter_width == 6 and rolloff == 0.99:  # device path: csrc/frontend.hip (same kernel table, fp32 FIR)
         from ..frontend import resample as _hip_resample
         return _hip_resample(waveform, orig_freq, new_freq)
-    g = math.gcd(int(orig_freq), int(new_freq))
-    orig, new = int(orig_freq) // g, int(new_freq) // g
-    base_freq = min(orig, new) * rolloff
-    width = math.ceil(lowpass_filter_width * orig / base_freq)
-    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
-    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
-    t = (t * base_freq).clamp(-lowpass_filter_width, lowpass_filter_width)
-    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
-    t = t * math.pi
-    kernels = torch.where(t == 0, torch.ones_like(t), torch.sin(t) / t) * window * (base_freq / orig)
-    kernels = kernels.to(waveform.dtype)
-    shape = waveform.shape
-    x = waveform.reshape(-1, shape[-1])
-    length = x.shape[-1]
-    x = torch.nn.functional.pad(x, (width, width + orig))
-    y = torch.nn.functional.conv1d(x[:, None], kernels, stride=orig)
-    y = y.transpose(1, 2).reshape(x.shape[0], -1)
-    target = int(math.ceil(new * length / orig))
-    return y[..., :target].reshape(shape[:-1] + (target,))
+    raise RuntimeError("resample: the waveform must be on the MI355X (libf5hip f5_frontend_resample, torchaudio's sinc_interp_hann with width 6 / "
+                       "rolloff 0.99); this package has no CPU path (the float64 restatement lives in oracle/cpu_ref.resample)")

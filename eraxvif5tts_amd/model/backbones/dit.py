@@ -303,7 +303,7 @@ class DiT(nn.Module):
         self._report_fallback(lib, plan)
         return out, traj
 
-    def native_sample_ragged(self, cond_cat, text, lens, frames, y0_cat, tgrid, steps, cfg_strength, method="euler"):
+    def native_sample_ragged(self, cond_cat, text, lens, frames, y0_cat, tgrid, steps, cfg_strength, method="euler", use_graph="auto"):
         """Utterances of different frame counts in ONE set of launches (include/f5hip.h: f5_sample_ragged).  cond_cat / y0_cat f32
         [sum(frames), mel] (the utterances one after the other), text int [B, nt] (-1 padded), lens int [B], frames list of ints.
         Returns out_cat [sum(frames), mel]; every utterance's rows equal its own batch-1 native_sample()."""
@@ -328,6 +328,13 @@ class DiT(nn.Module):
         out = torch.empty_like(cond_cat)
         meth = {"euler": _lib.F5_ODE_EULER, "midpoint": _lib.F5_ODE_MIDPOINT}[method]
         _lib.check(lib.f5_plan_set_option(plan, b"residual_guard", 1), "plan_set_option")
+        # a list of frame counts that recurs (batch inference over fixed buckets, a server's chunk pattern) replays its hipGraph from the second
+        # call on; one-off shapes run eagerly (capturing costs about one small sample())
+        key = ("ragged", tuple(int(f) for f in frames), int(text.shape[1]), steps, method, float(cfg_strength))
+        seen = self._seen_shapes.get(key, 0)
+        self._seen_shapes[key] = seen + 1
+        graph = seen >= 1 if use_graph == "auto" else bool(use_graph)
+        _lib.check(lib.f5_plan_set_option(plan, b"ragged_graph", int(graph)), "plan_set_option")
         _lib.check(lib.f5_sample_ragged(plan, B, C.c_void_p(fr.data_ptr()), _lib.ptr(cond_cat), _lib.ptr(ids), ids.shape[1], _lib.ptr(lens32),
                                         _lib.ptr(y0_cat), C.c_void_p(tg.data_ptr()), steps, float(cfg_strength), meth, _lib.ptr(out),
                                         _lib.stream_ptr()), "sample_ragged")

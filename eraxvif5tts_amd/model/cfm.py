@@ -129,7 +129,7 @@ class CFM(nn.Module):
 
     @torch.no_grad()
     def sample_ragged(self, cond, texts, durations, *, lens=None, steps=32, cfg_strength=1.0, sway_sampling_coef=None, seed=None,
-                      max_duration=4096, y0s=None, noise_device=None):
+                      max_duration=4096, y0s=None, noise_device=None, use_graph="auto"):
         """``sample()`` for several texts over ONE prompt, each with its own duration, in one set of kernel launches without padding the
         utterances to a common length (libf5hip ``f5_sample_ragged``).  Equivalent to ``[sample(cond, [t], d)[0] for t, d in zip(texts,
         durations)]`` -- the reference's batch-1 arithmetic per utterance (cfm.py:82-208 with batch = 1: no key mask), noise drawn in the
@@ -172,7 +172,8 @@ class CFM(nn.Module):
         t = torch.linspace(0, 1, steps + 1, device=self.device, dtype=cond.dtype)
         if sway_sampling_coef is not None:
             t = t + sway_sampling_coef * (torch.cos(torch.pi / 2 * t) - 1 + t)
-        out = native(torch.cat(conds), text, lens, frames, torch.cat(noises), t, steps, cfg_strength, method=self.odeint_kwargs.get("method", "euler"))
+        out = native(torch.cat(conds), text, lens, frames, torch.cat(noises), t, steps, cfg_strength, method=self.odeint_kwargs.get("method", "euler"),
+                     use_graph=use_graph)
         self.transformer.clear_cache()
         return [o.unsqueeze(0).to(cond.dtype) for o in torch.split(out, frames)]
 

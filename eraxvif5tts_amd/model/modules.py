@@ -4,28 +4,13 @@ Only the ``vocos`` mel type of the hot path is provided (the bigvgan variant bel
 torchaudio is not a dependency: ``MelSpectrogram(sr 24000, n_fft 1024, win 1024, hop 256, n_mels 100, power=1, center=True,
 norm=None, mel_scale='htk')`` is written out with ``torch.stft`` (periodic Hann, reflect padding) and the HTK triangular
 filterbank, then ``clamp(min=1e-5).log()``.  A waveform on the GPU -- the inference path: the wrapper keeps the prompt on the device --
-goes through libf5hip (``f5_frontend_mel``); the ``torch.stft`` form below only serves host-resident tensors.
+goes through libf5hip (``f5_frontend_mel``).  A host-resident waveform raises: the package has no CPU path (round 4: the ``torch.stft``
+form that used to serve the CPU tests is gone; its restatement lives in the oracle, ``oracle/cpu_ref.mel_spectrogram``).
 """
 from __future__ import annotations
 
-import math
-
 import torch
 from torch import nn
-
-
-def _hz_to_mel(f):
-    return 2595.0 * math.log10(1.0 + f / 700.0)
-
-
-def htk_filterbank(n_freqs, n_mels, sample_rate, f_min=0.0, f_max=None):
-    f_max = sample_rate / 2 if f_max is None else f_max
-    freqs = torch.linspace(0, sample_rate // 2, n_freqs)
-    m = torch.linspace(_hz_to_mel(f_min), _hz_to_mel(f_max), n_mels + 2)
-    f = 700.0 * (10.0 ** (m / 2595.0) - 1.0)
-    width = f[1:] - f[:-1]
-    slope = f[None, :] - freqs[:, None]
-    return torch.clamp(torch.minimum(-slope[:, :-2] / width[:-1], slope[:, 2:] / width[1:]), min=0.0)  # [n_freqs, n_mels]
 
 
 def get_vocos_mel_spectrogram(waveform, n_fft=1024, n_mel_channels=100, target_sample_rate=24000, hop_length=256, win_length=1024):
@@ -36,14 +21,7 @@ def get_vocos_mel_spectrogram(waveform, n_fft=1024, n_mel_channels=100, target_s
         from ..frontend import mel_spectrogram
         return mel_spectrogram(waveform, n_fft=n_fft, hop_length=hop_length, win_length=win_length, n_mel_channels=n_mel_channels,
                                target_sample_rate=target_sample_rate).to(waveform.dtype)
-    # host-resident waveforms (the reference is CPU-runnable too; only the CPU tests come here)
-    wav = waveform.float()
-    window = torch.hann_window(win_length, periodic=True, device=wav.device)
-    spec = torch.stft(wav, n_fft, hop_length=hop_length, win_length=win_length, window=window, center=True, pad_mode="reflect",
-                      normalized=False, onesided=True, return_complex=True).abs()
-    fb = htk_filterbank(n_fft // 2 + 1, n_mel_channels, target_sample_rate).to(wav.device)
-    mel = torch.matmul(spec.transpose(-1, -2), fb).transpose(-1, -2)
-    return mel.clamp(min=1e-5).log().to(waveform.dtype)
+    raise RuntimeError("MelSpec: the waveform must be on the MI355X (libf5hip f5_frontend_mel); this package has no CPU path")
 
 
 class MelSpec(nn.Module):

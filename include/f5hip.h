@@ -143,7 +143,8 @@ F5_API int f5_sample_finish(f5_plan_t p, f5_stream_t stream);
  * batch-1 f5_sample call: bit-identical output whenever both calls take the tuned kernels (every frames_host[i] >= 256, bf16 mode) or both the
  * fp32 mode's.  frames_host: host int32 [B]; cond, y0, out: dev f32 [sum(frames), mel], the utterances one after the other; text dev int32
  * [B, nt] (-1 padded); lens dev int32 [B] (prompt frames); no trajectory, no hipGraph (shapes rarely recur); DiT backbone only.
- * Plan capacity: sum(frames_i + 16, each rounded up to 16) <= max_batch * max_seq, every frames_i and nt <= max_seq, B <= max_batch. */
+ * Plan capacity: sum(frames_i + 16, each rounded up to 16) <= max_batch * max_seq, every frames_i and nt <= max_seq, B <= max_batch.  * Plan option "ragged_graph" = 1 (round 4): the call replays a hipGraph captured for this exact list of frame counts (+ nt, steps, method, CFG)
+ * -- batch inference over fixed length buckets (eval/prompts.py) meets the same bucket shapes again; 0 (default): eager launches. */
 F5_API int f5_sample_ragged(f5_plan_t p, int B, const int32_t* frames_host, const float* cond, const int32_t* text, int nt, const int32_t* lens,
                      const float* y0, const float* tgrid_host, int steps, float cfg_strength, int ode_method, float* out, f5_stream_t stream);
 

@@ -11,7 +11,34 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _memoize_weight_generators():
+    """The seeded weight generators of the oracle take ~5 s for a true-size network and are called with the same (arch, vocab, seed) by many
+    parametrizations: keep the last few results for the session (suite wall time).  Callers get a shallow copy; no test
+    mutates the tensors in place."""
+    import functools
+    import json
+
+    from oracle import cpu_ref
+
+    def memo(fn):
+        cache = {}
+
+        @functools.wraps(fn)
+        def wrapped(cfg, vocab_size, seed=0, **kw):
+            key = (json.dumps(cfg, sort_keys=True, default=str), int(vocab_size), int(seed), tuple(sorted(kw.items())))
+            if key not in cache:
+                if len(cache) >= 4:
+                    cache.pop(next(iter(cache)))
+                cache[key] = fn(cfg, vocab_size, seed=seed, **kw)
+            return dict(cache[key])
+        return wrapped
+    for name in ("random_dit_weights", "random_unett_weights", "random_mmdit_weights"):
+        if not hasattr(getattr(cpu_ref, name), "__wrapped__"):
+            setattr(cpu_ref, name, memo(getattr(cpu_ref, name)))
+
+
 def pytest_configure(config):
+    _memoize_weight_generators()
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
