@@ -71,6 +71,7 @@ _PROTOS = {
     "f5_duration_predict_g": (_I, [C.POINTER(DurationWeights), _I, _I, _P, _I, _P, _P, _I, _P, _P, _P]),
     "f5_op_linear": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
     "f5_op_linear_fused": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P]),
+    "f5_op_ln_fold": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P]),
     "f5_op_layernorm_modulate": (_I, [_I, _I, _P, _P, _P, _P, _P]),
     "f5_op_attention": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "f5_op_conv_pos_embed": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),

@@ -273,28 +273,23 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
     };
     // LayerNorm fold, producer side: partial row statistics of the 64 features this wave just stored for token row m (values h = the
     // fp16-ROUNDED stream elements, pivot = the row's previous mean): (sum (h - pivot), sum (h - pivot)^2) over the lane's 16 values, then over
-    // the four lanes that share the row (v_permlane16_swap / v_permlane32_swap butterflies: every lane ends with the same total); lane
-    // group 0 stores it.  The order of the additions is fixed and does not depend on the tile shape (a wave always owns 64 features).
+    // the four lanes that share the row (v_permlane16_swap, v_permlane32_swap); lane groups 0 / 1 store the two sums.  The order of the additions is fixed and does not depend on the tile shape (a wave always owns 64 features).
     [[maybe_unused]] auto emit_stats = [&](int m, bool row_ok, float pivot, const f32x4& h0, const f32x4& h1, const f32x4& h2, const f32x4& h3) {
         const f32x4 pv{pivot, pivot, pivot, pivot};
         const f32x4 d0 = h0 - pv, d1 = h1 - pv, d2 = h2 - pv, d3 = h3 - pv;
         const f32x4 a = (d0 + d1) + (d2 + d3);
         const f32x4 q = __builtin_elementwise_fma(d3, d3, __builtin_elementwise_fma(d2, d2, __builtin_elementwise_fma(d1, d1, d0 * d0)));
-        float s1 = (a[0] + a[1]) + (a[2] + a[3]), s2 = (q[0] + q[1]) + (q[2] + q[3]);
-        {
-            const u32x2 t1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s1), false, false);
-            const u32x2 t2 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, s2), __builtin_bit_cast(unsigned, s2), false, false);
-            s1 = __builtin_bit_cast(float, t1[0]) + __builtin_bit_cast(float, t1[1]);
-            s2 = __builtin_bit_cast(float, t2[0]) + __builtin_bit_cast(float, t2[1]);
-        }
-        {
-            const u32x2 t1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s1), false, false);
-            const u32x2 t2 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, s2), __builtin_bit_cast(unsigned, s2), false, false);
-            s1 = __builtin_bit_cast(float, t1[0]) + __builtin_bit_cast(float, t1[1]);
-            s2 = __builtin_bit_cast(float, t2[0]) + __builtin_bit_cast(float, t2[1]);
-        }
-        if (fq == 0 && row_ok)
-            *reinterpret_cast<f32x2*>(p.stats_out + ((size_t)((n0 + wn * WN) >> 6) * p.stats_ld + m) * 2) = f32x2{s1, s2};
+        const float s1 = (a[0] + a[1]) + (a[2] + a[3]), s2 = (q[0] + q[1]) + (q[2] + q[3]);
+        // The four lanes of a row sit in the four 16-lane rows of the wave.  v_permlane16_swap(s1, s2) -- two DIFFERENT registers: with the same
+        // value on both sides (round 4, first form) hipcc keeps one register for the two tied operands and the swap moves nothing, the sums
+        // then cover a quarter of the row -- leaves [s1 r0, s2 r0, s1 r2, s2 r2] and [s1 r1, s2 r1, s1 r3, s2 r3]: their sum holds s1 of rows
+        // 0+1 in row 0, s2 of rows 0+1 in row 1, the same for rows 2+3 in rows 2 / 3.  v_permlane32_swap against a zero register then brings the
+        // upper half under the lower one: row 0 ends with the total of s1, row 1 with the total of s2 = the two floats of the partial.
+        const u32x2 t16 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s2), false, false);
+        const float t = __builtin_bit_cast(float, t16[0]) + __builtin_bit_cast(float, t16[1]);
+        const u32x2 t32 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, t), 0u, false, false);
+        const float tot = __builtin_bit_cast(float, t32[0]) + __builtin_bit_cast(float, t32[1]);
+        if (fq < 2 && row_ok) p.stats_out[((size_t)((n0 + wn * WN) >> 6) * p.stats_ld + m) * 2 + fq] = tot;
     };
     [[maybe_unused]] auto h_round4 = [](const f32x4& v) {  // what the fp16 stream holds after a saturating store of v
         f32x4 r;

@@ -89,6 +89,60 @@ extern "C" int f5_op_linear_fused(int kernel, int epi, int M, int N, int K, cons
     return sync_and_release(a, st, rc);
 }
 
+// The LayerNorm fold of one call site end to end (parity tests; gemm.h, lnfold.hip).  `x` [M, D] is the fp16 residual stream, handed over and
+// returned as f32: (1) x += gate * (A . Wo^T + bo) in place with partial row statistics (EPI_RESID + stats_out; pivots = column 0 of `pivot`
+// [M][2] or none), (2) stats_finalize -> `stats` [M][2] = (mean, rstd), (3) W' / c1 / c2 from W [N, D], bias, scale, shift (fold_weights_kernel),
+// (4) out [M, N] = epilogue(rstd (x . W'^T - mean c1) + c2): epi 0 = store with `act` (FF1: GELU tanh), epi 4 = RoPE (fused QKV, N = 3 * inner).
+extern "C" int f5_op_ln_fold(int epi, int M, int D, int N, int Kb, float* x, const float* A, const float* Wo, const float* bo, const float* gate,
+                             const float* pivot, const float* W, const float* bias, const float* scale, const float* shift, int act,
+                             const float* rope, int rope_heads, int seq, float* stats, float* out, f5_stream_t stream) {
+    F5_TRY(f5_check_device());
+    if (M <= 0 || D <= 0 || N <= 0 || Kb <= 0 || !x || !A || !Wo || !bo || !W || !bias || !scale || !shift || !stats || !out) return f5_fail(F5_EINVAL, "bad argument");
+    if (D % 128 != 0 || Kb % 32 != 0 || N % 64 != 0 || (epi != EPI_STORE_T && epi != EPI_ROPE_T)) return f5_fail(F5_EINVAL, "f5_op_ln_fold: D % 128, Kb % 32, N % 64, epi 0 | 4");
+    if (epi == EPI_ROPE_T && (!rope || seq <= 0 || M % seq != 0 || N % 3 != 0 || (N / 3) % 64 != 0)) return f5_fail(F5_EINVAL, "bad RoPE arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t Mp = round_up(M, 256) + 256;
+    DevArena a;
+    void *At = nullptr, *Wot = nullptr, *xs = nullptr, *Wt = nullptr, *Ot = nullptr;
+    float *partial = nullptr, *st2 = nullptr, *mod = nullptr, *c1 = nullptr, *c2 = nullptr;
+    int rc = 0;
+    do {
+        if ((rc = a.alloc(&At, Mp * Kb * 2))) break;
+        if ((rc = a.alloc(&Wot, (size_t)round_up(D, 256) * Kb * 2))) break;
+        if ((rc = a.alloc(&xs, Mp * D * 2))) break;
+        if ((rc = a.alloc(&Wt, (size_t)round_up(N, 256) * D * 2))) break;
+        if ((rc = a.alloc(&Ot, Mp * N * 2))) break;
+        if ((rc = a.alloc_t(&partial, (size_t)(D / 64) * Mp * 2))) break;
+        if ((rc = a.alloc_t(&st2, Mp * 2))) break;
+        if ((rc = a.alloc_t(&mod, (size_t)6 * D))) break;
+        if ((rc = a.alloc_t(&c1, (size_t)N))) break;
+        if ((rc = a.alloc_t(&c2, (size_t)N))) break;
+        if ((rc = launch_convert_pad(F5_PREC_BF16, A, Kb, M, Kb, Kb, At, Kb, st))) break;
+        if ((rc = launch_convert_pad(F5_PREC_BF16, Wo, Kb, D, Kb, Kb, Wot, Kb, st))) break;
+        if ((rc = launch_f32_to_f16(x, xs, (size_t)M * D, st))) break;
+        if (pivot) F5_HIP(hipMemcpyAsync(st2, pivot, (size_t)M * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        F5_HIP(hipMemcpyAsync(mod, shift, (size_t)D * sizeof(float), hipMemcpyDeviceToDevice, st));      // (shift_msa, scale_msa) slots of one block
+        F5_HIP(hipMemcpyAsync(mod + D, scale, (size_t)D * sizeof(float), hipMemcpyDeviceToDevice, st));
+        GemmParams g;
+        memset(&g, 0, sizeof(g));
+        g.A = At; g.lda = Kb; g.W = Wot; g.ldw = Kb; g.M = M; g.N = D; g.K = Kb; g.bias = bo; g.rows_per_batch = seq > 0 ? seq : M;
+        g.out_f = reinterpret_cast<float*>(xs); g.ldof = D; g.add2_f16 = 1; g.gate = gate;
+        g.stats_out = partial; g.stats_ld = (int)Mp; g.stats_pivot = pivot ? st2 : nullptr;
+        if ((rc = launch_gemm(g, F5_PREC_BF16, GEMM_DENSE, EPI_RESID, 1, st))) break;
+        if ((rc = launch_stats_finalize(partial, (int)Mp, D / 64, M, D, pivot ? st2 : nullptr, st2, nullptr, 0, st))) break;
+        if ((rc = launch_fold_weights(W, bias, mod, 6 * D, 1, 1, N, N, D, Wt, c1, c2, st))) break;
+        memset(&g, 0, sizeof(g));
+        g.A = xs; g.lda = D; g.W = Wt; g.ldw = D; g.M = M; g.N = N; g.K = D; g.act = act; g.out_t = Ot; g.ldo = N; g.rows_per_batch = seq > 0 ? seq : M;
+        g.lnf_stats = st2; g.lnf_c1 = c1; g.lnf_c2 = c2;
+        if (epi == EPI_ROPE_T) { g.rope = rope; g.rope_inner = N / 3; g.rope_heads = rope_heads; }
+        if ((rc = launch_gemm(g, F5_PREC_BF16, GEMM_DENSE, epi, 1, st))) break;
+        if ((rc = launch_f16_to_f32(xs, x, (size_t)M * D, st))) break;
+        F5_HIP(hipMemcpyAsync(stats, st2, (size_t)M * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        rc = launch_convert_back(F5_PREC_BF16, Ot, N, M, N, out, N, st);
+    } while (0);
+    return sync_and_release(a, st, rc);
+}
+
 extern "C" int f5_op_layernorm_modulate(int rows, int dim, const float* x, const float* scale, const float* shift, float* out,
                                         f5_stream_t stream) {
     F5_TRY(f5_check_device());

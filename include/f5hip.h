@@ -237,6 +237,14 @@ F5_API int f5_op_linear(int precision, int kernel, int M, int N, int K, const fl
 F5_API int f5_op_linear_fused(int kernel, int epi, int M, int N, int K, const float* A, const float* W, const float* bias, int act,
                        const float* gate, const uint8_t* rowmask, const float* rope, int rope_heads, int seq, float* out,
                        f5_stream_t stream);
+/* The LayerNorm fold of one call site end to end (round 4; parity tests).  x [M, D]: the fp16 residual stream, handed over and returned as f32.
+ * (1) x += gate * (A . Wo^T + bo) in place by the tuned GEMM's EPI_RESID epilogue, which also writes partial row sums of the values it stores
+ * (pivot = column 0 of `pivot` [M][2], or NULL); (2) stats [M][2] = (mean, rstd) of every row, eps 1e-6 (modules.py:308,624); (3) W' = fp16(W (1 +
+ * scale)), c1 = rowsum W', c2 = bias + W . shift; (4) out [M, N] = epilogue(rstd (x . W'^T - mean c1) + c2) on v_mfma_f32_16x16x32_f16 --
+ * epi 0: store with `act` (FF1 + GELU: modules.py:258-264, 637-638), epi 4: RoPE on the q | k columns (fused QKV: modules.py:301-317, 452-480). */
+F5_API int f5_op_ln_fold(int epi, int M, int D, int N, int Kb, float* x, const float* A, const float* Wo, const float* bo, const float* gate,
+                         const float* pivot, const float* W, const float* bias, const float* scale, const float* shift, int act, const float* rope,
+                         int rope_heads, int seq, float* stats, float* out, f5_stream_t stream);
 /* LayerNorm(eps 1e-6, no affine) * (1 + scale) + shift ; x f32 [rows, dim]; scale/shift f32 [dim] */
 F5_API int f5_op_layernorm_modulate(int rows, int dim, const float* x, const float* scale, const float* shift, float* out,
                              f5_stream_t stream);

@@ -82,3 +82,17 @@ def op_ln_mod(x, scale, shift):
 
 def bf16_round(t):
     return t.to(torch.bfloat16).float()
+
+
+def op_ln_fold(epi, x, A, Wo, bo, gate, W, bias, scale, shift, pivot=None, act="none", rope=None, rope_heads=0, seq=0):
+    """include/f5hip.h: f5_op_ln_fold.  Returns (updated fp16 stream as f32 [M, D], stats [M, 2] = (mean, rstd), out [M, N])."""
+    lib = _lib.load()
+    M, D = x.shape
+    N, Kb = W.shape[0], A.shape[1]
+    dev = [None if t is None else t.cuda().float().contiguous() for t in (A, Wo, bo, gate, pivot, W, bias, scale, shift, rope)]
+    xs = x.cuda().float().contiguous().clone()
+    stats = torch.empty(M, 2, device="cuda")
+    out = torch.empty(M, N, device="cuda")
+    _lib.check(lib.f5_op_ln_fold(epi, M, D, N, Kb, _lib.ptr(xs), *[_lib.ptr(t) for t in dev[:9]], _lib.ACT[act], _lib.ptr(dev[9]), rope_heads, seq,
+                                 _lib.ptr(stats), _lib.ptr(out), _lib.stream_ptr()))
+    return xs.cpu(), stats.cpu(), out.cpu()

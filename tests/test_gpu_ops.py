@@ -447,3 +447,64 @@ def test_attention_tuned_kernel_spiked_scores():
     ref = _attn_ref(qkv, None)
     out = G.op_attention(P_BF16, 1, qkv, None)
     assert rel_l2(out, ref) < 6e-3
+
+
+@pytest.mark.parametrize("M,D,N,Kb,epi", [
+    (300, 128, 384, 128, 4),     # tiny-arch QKV: ragged token tile, 128-wide feature tiles
+    (300, 128, 256, 256, 0),     # tiny-arch FF1 (GELU)
+    (1024, 1024, 3072, 1024, 4),  # F5TTS_Base QKV: persistent 256 x 256 tiles (stats from the out-projection's persistent in-place epilogue)
+    (1024, 1024, 2048, 2048, 0),  # F5TTS_Base FF1 behind an FF2-shaped producer
+    (1100, 1024, 2048, 1024, 0),  # M % 256 != 0: whole tiles on the persistent schedule + a tail launch
+    (512, 1024, 3072, 1024, 4),   # fewer tiles than CUs
+])
+@pytest.mark.parametrize("offset", [0.0, 40.0])
+def test_layernorm_fold_site_against_fp64(M, D, N, Kb, epi, offset):
+    """The LayerNorm fold of one call site (modules.py:301-317 / 637-638 folded into the projection behind it; gemm.h) against fp64 math:
+    (1) the in-place residual epilogue updates the fp16 stream, (2) its partial row sums give (mean, rstd) of the STORED rows -- also with a
+    common offset of 40 standard deviations on every row, where a plain sum-of-squares form would lose its digits: the pivot is the row's
+    previous mean --, (3) Linear(LN(x) (1 + scale) + shift) comes out of the fp16 GEMM + fold epilogue with bf16 output rounding only."""
+    import gpu_helpers as G
+    g = torch.Generator().manual_seed(M + N + int(offset))
+    x = torch.randn(M, D, generator=g) * 1.7 + offset + torch.randn(M, 1, generator=g) * 0.5
+    A = G.bf16_round(torch.randn(M, Kb, generator=g))
+    Wo = G.bf16_round(torch.randn(D, Kb, generator=g) / Kb ** 0.5)
+    bo = torch.randn(D, generator=g) * 0.1
+    gate = torch.randn(D, generator=g) * 0.3
+    W = torch.randn(N, D, generator=g) / D ** 0.5
+    bias = torch.randn(N, generator=g) * 0.1
+    scale, shift = torch.randn(D, generator=g) * 0.2, torch.randn(D, generator=g) * 0.3
+    seq = M // 2 if epi == 4 and M % 2 == 0 else M
+    rope = None
+    if epi == 4:
+        ang = torch.arange(seq)[:, None] * (1.0 / 10000.0 ** (torch.arange(0, 64, 2) / 64.0))[None, :]
+        rope = torch.stack([ang.cos(), ang.sin()], dim=-1).reshape(seq, 64).float()
+    xh = x.half().float()
+    pivot = torch.stack([xh.mean(dim=1) + 0.01, torch.ones(M)], dim=1) if offset else None  # "previous mean": near, not equal to, the new one
+    xs, stats, out = G.op_ln_fold(epi, x, A, Wo, bo, gate, W, bias, scale, shift, pivot=pivot, act="gelu_tanh" if epi == 0 else "none", rope=rope,
+                                  rope_heads=1, seq=seq)
+    # (1) the stream: x + gate * (A Wo^T + bo), stored as fp16
+    want = xh.double() + gate.double() * (A.double() @ Wo.double().t() + bo.double())
+    assert (xs.double() - want).abs().max() <= want.abs().max() * 2.0 ** -10  # within one fp16 ulp of the exact sum
+    # (2) statistics of the STORED rows
+    mean, var = xs.double().mean(dim=1), xs.double().var(dim=1, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-6)
+    assert (stats[:, 0].double() - mean).abs().max() < 2e-5 * (1 + mean.abs().max())
+    assert ((stats[:, 1].double() - rstd) / rstd).abs().max() < 2e-4
+    # (3) the folded projection
+    h = (xs.double() - mean[:, None]) * rstd[:, None] * (1 + scale.double()) + shift.double()
+    ref = h @ W.double().t() + bias.double()
+    if epi == 0:
+        ref = 0.5 * ref * (1 + torch.tanh(0.7978845608028654 * (ref + 0.044715 * ref ** 3)))
+    else:
+        inner = N // 3
+        r = ref.clone()
+        pos = torch.arange(M) % seq
+        cs = rope.double()[pos].reshape(M, 32, 2)
+        for part in (0, 1):
+            blk = ref[:, part * inner: part * inner + 64].reshape(M, 32, 2)
+            rot = torch.stack([blk[..., 0] * cs[..., 0] - blk[..., 1] * cs[..., 1], blk[..., 1] * cs[..., 0] + blk[..., 0] * cs[..., 1]], dim=-1)
+            r[:, part * inner: part * inner + 64] = rot.reshape(M, 64)
+        ref = r
+    err = rel_l2(out, ref)
+    print(f"ln_fold M={M} D={D} N={N} epi={epi} offset={offset}: rel-L2 {err:.2e}")
+    assert err < 3e-3  # bf16 output rounding (2^-9 relative per element) + fp16 rounding of W'
