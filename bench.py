@@ -237,6 +237,8 @@ def insitu_kernels(model, cfm, batch, B, N, nfe, args):
         a, n = C.c_float(0.0), C.c_int(0)
         _lib.check(lib.f5_plan_timing_site(plan, i, C.byref(a), C.byref(n)), "timing_site")
         return a.value, n.value
+    fold = C.c_int(0)
+    _lib.check(lib.f5_plan_get_option(plan, b"ln_fold_active", C.byref(fold)), "plan_get_option")
     es = 2 if args.precision == "bf16" else 4
     xs = es  # storage bytes of a residual-stream element: fp16 in the bf16 production mode (blocks 1..21 of 22; the first reads fp32), fp32 otherwise
     work = {  # algorithmic work per launch: FLOP for the MFMA-bound kernels, bytes for the HBM-bound ones
@@ -250,6 +252,13 @@ def insitu_kernels(model, cfm, batch, B, N, nfe, args):
         "ln1": ("hbm", rows * D * ((xs + es) if args.precision == "bf16" else (xs + es + es))),
         "ln2": ("hbm", rows * D * ((xs + es) if args.precision == "bf16" else (xs + es + es + xs + es))),
     }
+    if fold.value:
+        # LayerNorm fold (round 4): the two passes of a block are gone; what runs at these sites is stats_finalize_kernel -- per token row it reads the
+        # D / 64 partial sums (float2) the in-place residual epilogue in front wrote and the row's pivot, and writes (mean, rstd).  Block 0's first
+        # site is still a LayerNorm pass (1 of its 22 launches per evaluation); it is averaged in with its own byte count.
+        fin = rows * ((D // 64) * 8 + 8 + 8)
+        work["ln1"] = ("hbm", (fin * (depth - 1) + work["ln1"][1]) / depth)
+        work["ln2"] = ("hbm", fin)
     kernels = []
     for i, name in enumerate(_lib.SITES):
         t_ms, n = site(i)
@@ -262,6 +271,8 @@ def insitu_kernels(model, cfm, batch, B, N, nfe, args):
                             "launches": n, "achieved": round(a, 1), "unit": "TFLOP/s", "frac": round(a / MFMA_BF16_PEAK_TFLOPS, 4)})
         else:
             a = w / (t_ms * 1e-3) / 1e9
+            if fold.value and name in ("ln1", "ln2"):
+                name += " (LayerNorm folded: row-statistics finalize)"
             kernels.append({"kernel": name, "bound": "hbm", "work": round(w / 1e6, 1), "work_unit": "MB", "ms": round(t_ms, 4),
                             "launches": n, "achieved": round(a, 1), "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4)})
     return ms.value, cnt.value, flops_qkv, kernels

@@ -74,6 +74,16 @@ int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, const float
         PrefetchSet pf1{{b.w_o, b.w_ff1, nullptr, nullptr}, {(unsigned)(D * inner * wes), (unsigned)(ff * D * wes), 0u, 0u}};
         PrefetchSet pf2{{b.w_ff2, l + 1 < c.depth ? m->blocks[l + 1].w_qkv : nullptr, nullptr, nullptr},
                         {(unsigned)(D * ff * wes), (unsigned)(3 * inner * D * wes), 0u, 0u}};
+        // (LayerNorm fold: the statistics kernels sit where the passes sat and prefetch what runs behind THEM -- the one behind the out-projection
+        //  this block's W' rows of ff.0.0 and the FF2 weight, the one behind FF2 the next block's W' rows of q|k|v and its out-projection weight)
+        PrefetchSet pf2f{{nullptr, nullptr, nullptr, nullptr}, {0u, 0u, 0u, 0u}}, pf1f = pf2f;
+        if (lnf) {
+            pf2f = PrefetchSet{{(const char*)ft->Wt + (frow0 + (size_t)l * fR + 3 * inner) * D * 2, b.w_ff2, nullptr, nullptr},
+                               {(unsigned)((size_t)ff * D * 2), (unsigned)(D * ff * wes), 0u, 0u}};
+            if (l + 1 < c.depth)
+                pf1f = PrefetchSet{{(const char*)ft->Wt + (frow0 + (size_t)(l + 1) * fR) * D * 2, m->blocks[l + 1].w_o, nullptr, nullptr},
+                                   {(unsigned)((size_t)3 * inner * D * 2), (unsigned)(D * inner * wes), 0u, 0u}};
+        }
         const bool lnf1 = lnf && l > 0;  // this block's first LayerNorm is folded into its QKV projection (statistics: the previous block's FF2)
         const char* fW = lnf ? (const char*)ft->Wt + (frow0 + (size_t)l * fR) * D * 2 : nullptr;  // this block's W' rows: q|k|v, then ff.0.0
         const float *fc1 = lnf ? ft->c1 + frow0 + (size_t)l * fR : nullptr, *fc2 = lnf ? ft->c2 + frow0 + (size_t)l * fR : nullptr;
@@ -174,7 +184,8 @@ int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, const float
         F5_TRY(timed(p, F5_SITE_OUT, st, [&] { return run_gemm(p, g, GEMM_DENSE, rmw ? EPI_RESID : EPI_GATE_T, st); }));
         // x += y; n2 = LN(x) * (1 + scale_mlp) + shift_mlp
         if (lnf) F5_TRY(timed(p, F5_SITE_LN2, st, [&] {
-            return launch_stats_finalize(p->lnf_partial, (int)p->rows_cap, D / 64, rows, D, l > 0 ? p->lnf_stats : nullptr, p->lnf_stats, sat, 2 | (l << 4), st);
+            return launch_stats_finalize(p->lnf_partial, (int)p->rows_cap, D / 64, rows, D, l > 0 ? p->lnf_stats : nullptr, p->lnf_stats, sat, 2 | (l << 4), st,
+                                         wpf ? &pf2f : nullptr);
         }));
         if (!lnf) F5_TRY(timed(p, F5_SITE_LN2, st, [&] {
             if (rmw)
@@ -207,7 +218,8 @@ int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, const float
         }
         F5_TRY(timed(p, F5_SITE_FF2, st, [&] { return run_gemm(p, g, GEMM_DENSE, rmw ? EPI_RESID : EPI_GATE_T, st); }));
         if (lnf_next) F5_TRY(timed(p, F5_SITE_LN1, st, [&] {
-            return launch_stats_finalize(p->lnf_partial, (int)p->rows_cap, D / 64, rows, D, p->lnf_stats, p->lnf_stats, sat, 1 | ((l + 1) << 4), st);
+            return launch_stats_finalize(p->lnf_partial, (int)p->rows_cap, D / 64, rows, D, p->lnf_stats, p->lnf_stats, sat, 1 | ((l + 1) << 4), st,
+                                         wpf ? &pf1f : nullptr);
         }));
     }
     const float* mf = modp + (size_t)c.depth * 6 * D;  // final AdaLN: (scale, shift) (modules.py:333)

@@ -184,6 +184,12 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
     // build spilled with them in registers).  Persistent schedule: the area is the start of the wave's OWN activation pieces in the ring slot
     // the DMA front writes next (it holds no live stage; only this wave writes there again, behind its own reads in program order, so no
     // barrier is involved).  Other schedules: the ring is dead after the main loop (one barrier), the area is smem + wave * 2048.
+    // Tiles with at most 4 token tiles per wave (every tile but the 256-wide one) have the registers to HOLD the operands instead (40 at most):
+    // they are loaded with the other per-tile epilogue operands before the main loop, nothing is exposed and no barrier is needed -- the small
+    // launches that take these tiles are latency-bound.
+    constexpr bool LNF_LDS = LNF && (WM / 16) >= 8;
+    [[maybe_unused]] f32x4 c1r[LNF && !LNF_LDS ? NI : 1], c2r[LNF && !LNF_LDS ? NI : 1];
+    [[maybe_unused]] f32x2 lstr[LNF && !LNF_LDS ? WM / 16 : 1];
     [[maybe_unused]] char* lnf_lds = nullptr;
     [[maybe_unused]] auto stage_lnf = [&](int tm0, int tn0, char* area) {
         lnf_lds = area;
@@ -196,6 +202,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
             __builtin_amdgcn_global_load_lds((gptr_t)(p.lnf_stats + ((size_t)(tm0 + wm * WM) + 2 * lane) * 2), (lptr_t)(lnf_lds + 512), 16, 0, 0);
     };
     [[maybe_unused]] auto lnf_apply = [&](const f32x4& a, int i, int j) {
+        if constexpr (LNF && !LNF_LDS) return epi_lnf4(a, lstr[j][0], lstr[j][1], c1r[i], c2r[i]);
         const f32x4 c1 = *reinterpret_cast<const f32x4*>(lnf_lds + (i * 16 + 4 * fq) * 4);
         const f32x4 c2 = *reinterpret_cast<const f32x4*>(lnf_lds + 256 + (i * 16 + 4 * fq) * 4);
         const f32x2 st = *reinterpret_cast<const f32x2*>(lnf_lds + 512 + (j * 16 + fr) * 8);
@@ -227,6 +234,19 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
         // 16-byte paired stores: after pair_swap a lane in 16-lane row r owns features (r&1 ? tile i+1 : tile i) * 16 + 8*(r>>1) .. +7
         wide_ok = (n0 + wn * WN + WN <= p.N) && (p.ldo & 7) == 0;
         nwide = n0 + wn * WN + 16 * (fq & 1) + 8 * (fq >> 1);
+        if constexpr (LNF && !LNF_LDS) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                c1r[i] = *reinterpret_cast<const f32x4*>(p.lnf_c1 + ncol[i]);
+                c2r[i] = *reinterpret_cast<const f32x4*>(p.lnf_c2 + ncol[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < WM / 16; ++j) {
+                int m = m0 + wm * WM + j * 16 + fr;
+                m = m < p.M ? m : p.M - 1;
+                lstr[j] = *reinterpret_cast<const f32x2*>(p.lnf_stats + (size_t)m * 2);
+            }
+        }
     };
     prep_epilogue();
 
@@ -280,15 +300,18 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
         const f32x4 a = (d0 + d1) + (d2 + d3);
         const f32x4 q = __builtin_elementwise_fma(d3, d3, __builtin_elementwise_fma(d2, d2, __builtin_elementwise_fma(d1, d1, d0 * d0)));
         const float s1 = (a[0] + a[1]) + (a[2] + a[3]), s2 = (q[0] + q[1]) + (q[2] + q[3]);
-        // The four lanes of a row sit in the four 16-lane rows of the wave.  v_permlane16_swap(s1, s2) -- two DIFFERENT registers: with the same
-        // value on both sides (round 4, first form) hipcc keeps one register for the two tied operands and the swap moves nothing, the sums
-        // then cover a quarter of the row -- leaves [s1 r0, s2 r0, s1 r2, s2 r2] and [s1 r1, s2 r1, s1 r3, s2 r3]: their sum holds s1 of rows
-        // 0+1 in row 0, s2 of rows 0+1 in row 1, the same for rows 2+3 in rows 2 / 3.  v_permlane32_swap against a zero register then brings the
-        // upper half under the lower one: row 0 ends with the total of s1, row 1 with the total of s2 = the two floats of the partial.
-        const u32x2 t16 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s2), false, false);
-        const float t = __builtin_bit_cast(float, t16[0]) + __builtin_bit_cast(float, t16[1]);
-        const u32x2 t32 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, t), 0u, false, false);
-        const float tot = __builtin_bit_cast(float, t32[0]) + __builtin_bit_cast(float, t32[1]);
+        // The four lanes of a row sit in the four 16-lane rows of the wave.  v_permlane16_swap(s1, s2) leaves [s1 r0, s2 r0, s1 r2, s2 r2] and
+        // [s1 r1, s2 r1, s1 r3, s2 r3]: their sum holds s1 of rows 0+1 in row 0, s2 of rows 0+1 in row 1, the same for rows 2+3 in rows 2 / 3.
+        // v_permlane32_swap against a zero register then brings the upper half under the lower one: row 0 ends with the total of s1, row 1 with
+        // the total of s2 = the two floats of the partial.  INLINE ASM on purpose: with the builtin, hipcc (ROCm 7.2) adds result 0 to ITSELF
+        // when the two results of a swap feed one add ("v_permlane16_swap v70, v66; v_add_f32 v66, v70, v70" in the .s of round 4's first
+        // build: the sums then covered a quarter of every row, which the op-level fp64 test caught).  s_nop 1: the wait states the compiler's
+        // hazard recogniser puts between a vector write of the operands and the swap; it does not look inside an asm statement.
+        float a0 = s1, b0 = s2;
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a0), "+v"(b0));
+        float t = a0 + b0, z = 0.0f;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(t), "+v"(z));
+        const float tot = t + z;
         if (fq < 2 && row_ok) p.stats_out[((size_t)((n0 + wn * WN) >> 6) * p.stats_ld + m) * 2 + fq] = tot;
     };
     [[maybe_unused]] auto h_round4 = [](const f32x4& v) {  // what the fp16 stream holds after a saturating store of v
@@ -638,7 +661,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
         return ok;
     };
     auto epilogue = [&]() {
-        if constexpr (LNF && !P30) {  // the ring is dead once every wave has retired its last fragment reads
+        if constexpr (LNF_LDS && !P30) {  // the ring is dead once every wave has retired its last fragment reads
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             stage_lnf(m0, n0, smem + wave * 2048);

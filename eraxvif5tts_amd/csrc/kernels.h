@@ -114,5 +114,5 @@ int launch_fold_weights(const float* W, const float* bias, const float* mod, int
                         float* c1, float* c2, hipStream_t stream);
 // partial row sums of an in-place residual GEMM ([ncols][ld] float2 planes) -> stats[row] = (mean, rstd); also the fp16 range guard of the stream
 int launch_stats_finalize(const float* partial, int ld, int ncols, int rows, int D, const float* pivot, float* stats, unsigned* sat, int sat_tag,
-                          hipStream_t stream);
+                          hipStream_t stream, const PrefetchSet* prefetch = nullptr /* weights of the launches behind it (small launches) */);
 

@@ -68,19 +68,44 @@ int launch_fold_weights(const float* W, const float* bias, const float* mod, int
     return 0;
 }
 
-// one thread per token row: partial[c * ld + row] = (s1, s2) of feature tile c (ncols = D / 64), added in the order c = 0, 1, ... (fixed)
+// one thread per token row: partial[c * ld + row] = (s1, s2) of feature tile c (ncols = D / 64), added in the order c = 0, 1, ... (fixed).
+// NC > 0: the column count as a constant, so that all NC loads of a row are in flight together (D = 1024: 16; the runtime loop issued them
+// one behind the other, 10 us per launch at 65 536 rows against 3 for the bytes).  Blocks past the row blocks only PREFETCH: small launches
+// are bound by the latency of the weights behind them, which every block reads from HBM again; as the LayerNorm passes of round 2 did, one
+// dword per 128-byte line of up to four weight ranges is touched here (thread t of prefetch block b: line 256 b + t of every range).
+template <int NC>
 __global__ __launch_bounds__(256) void stats_finalize_kernel(const f32x2_t* __restrict__ partial, int ld, int ncols, int rows, int D,
                                                              const float* pivot /* [rows][2] or null; may alias `stats` */, float* stats, unsigned* sat,
-                                                             int sat_tag) {
+                                                             int sat_tag, int row_blocks, PrefetchSet pf) {
+    if ((int)blockIdx.x >= row_blocks) {
+        const unsigned line = (blockIdx.x - (unsigned)row_blocks) * 256u + threadIdx.x;
+        unsigned acc = 0u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (pf.p[r] && (size_t)line * 128u < pf.n[r]) acc ^= *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(pf.p[r]) + (size_t)line * 128);
+        if (acc == 0x7fc0dead && line == 0xffffffffu) stats[0] = 0.f;  // (never true: keeps the loads alive)
+        return;
+    }
     const int row = blockIdx.x * 256 + threadIdx.x;
     bool bad = false;
     float sumsq = 0.f;
     if (row < rows) {
         float s1 = 0.f, s2 = 0.f;
-        for (int c = 0; c < ncols; ++c) {
-            const f32x2_t v = partial[(size_t)c * ld + row];
-            s1 += v[0];
-            s2 += v[1];
+        if constexpr (NC > 0) {
+            f32x2_t v[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) v[c] = partial[(size_t)c * ld + row];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                s1 += v[c][0];
+                s2 += v[c][1];
+            }
+        } else {
+            for (int c = 0; c < ncols; ++c) {
+                const f32x2_t v = partial[(size_t)c * ld + row];
+                s1 += v[0];
+                s2 += v[1];
+            }
         }
         const float pv = pivot ? pivot[(size_t)row * 2] : 0.0f;
         const float inv = 1.0f / (float)D;
@@ -107,10 +132,22 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const f32x2_t* __re
 }
 
 int launch_stats_finalize(const float* partial, int ld, int ncols, int rows, int D, const float* pivot, float* stats, unsigned* sat, int sat_tag,
-                          hipStream_t stream) {
+                          hipStream_t stream, const PrefetchSet* prefetch) {
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<const f32x2_t*>(partial), ld,
-                       ncols, rows, D, pivot, stats, sat, sat_tag);
+    PrefetchSet pf{{nullptr, nullptr, nullptr, nullptr}, {0u, 0u, 0u, 0u}};
+    unsigned pf_bytes = 0;
+    if (prefetch) {
+        pf = *prefetch;
+        for (int r = 0; r < 4; ++r)
+            if (pf.p[r] && pf.n[r] > pf_bytes) pf_bytes = pf.n[r];
+    }
+    const int row_blocks = (rows + 255) / 256, pf_blocks = (int)((pf_bytes / 128u + 255u) / 256u);
+    const dim3 grid((unsigned)(row_blocks + pf_blocks)), block(256);
+    const f32x2_t* pp = reinterpret_cast<const f32x2_t*>(partial);
+    if (ncols == 16)
+        hipLaunchKernelGGL(stats_finalize_kernel<16>, grid, block, 0, stream, pp, ld, ncols, rows, D, pivot, stats, sat, sat_tag, row_blocks, pf);
+    else
+        hipLaunchKernelGGL(stats_finalize_kernel<0>, grid, block, 0, stream, pp, ld, ncols, rows, D, pivot, stats, sat, sat_tag, row_blocks, pf);
     F5_LAUNCH_CHECK();
     return 0;
 }

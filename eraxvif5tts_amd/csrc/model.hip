@@ -600,6 +600,8 @@ extern "C" int f5_plan_get_option(f5_plan_t p, const char* key, int* value) {
         *value = p->sat_check;
     else if (strcmp(key, "ragged_graph") == 0)
         *value = p->ragged_graph;
+    else if (strcmp(key, "ln_fold_active") == 0)  // the staged time grid has a LayerNorm-fold table and the knob is on (what the next sample() runs)
+        *value = (p->fold && g_ln_fold) ? 1 : 0;
     else if (strcmp(key, "residual_fallbacks") == 0)
         *value = p->fallbacks;
     else if (strcmp(key, "residual_guard_amax_bits") == 0)  // diagnostic: float bits of the largest finite |element| the last event saw

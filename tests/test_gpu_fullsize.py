@@ -119,6 +119,44 @@ def test_true_depth_bf16_sampler_stays_within_tolerance_of_fp32_mode():
     assert torch.isfinite(outs["bf16"]).all() and err < 2e-2
 
 
+def test_layernorm_fold_against_the_unfolded_path_and_fp32_mode():
+    """Round 4: the LayerNorm fold (QKV / FF1 read the fp16 stream against per-time fp16 weights, statistics from the in-place residual
+    epilogues) against the round-3 path with two LayerNorm passes per block (knob ln_fold = 0) and against the exact-fp32
+    mode, F5TTS_Base depth, B = 2 with a key mask, N = 1024, NFE 8, CFG 2.  The fold must be at least as close to fp32 as the passes were
+    (it rounds less: no bf16 copy of the normalised rows, fp16 instead of bf16 weights), and eager == graph replay bit for bit."""
+    import bench
+    from eraxvif5tts_amd import _lib
+    from eraxvif5tts_amd.model import CFM, DiT
+    lib = _lib.load()
+    B, N = 2, 1024
+    cond, text, lens, dur = bench.synth_batch(B, N, "cuda", seed=19)
+    dur[1] = 870
+    g = torch.Generator().manual_seed(20)
+    y0 = torch.randn(B, N, 100, generator=g)
+    y0[1, 870:] = 0
+    kw = dict(cond=cond, text=text, duration=dur, lens=lens, steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, y0=y0, return_trajectory=False)
+    outs = {}
+    for tag, prec, fold in (("fp32", "fp32", 1), ("fold", "bf16", 1), ("passes", "bf16", 0)):
+        _lib.check(lib.f5_tuning_set(b"ln_fold", fold))
+        try:
+            torch.manual_seed(1234)
+            model = bench.synth_weights(DiT(**bench.BASE_ARCH, text_num_embeds=bench.VOCAB, mel_dim=100, precision=prec), seed=0)
+            cfm = CFM(transformer=model, mel_spec_kwargs={"mel_spec_type": "vocos"}).cuda()
+            outs[tag] = cfm.sample(use_graph=False, **kw)[0].cpu()
+            if tag == "fold":
+                assert torch.equal(cfm.sample(use_graph=True, **kw)[0].cpu(), outs[tag])
+                assert model.residual_fallbacks() == 0
+        finally:
+            _lib.check(lib.f5_tuning_set(b"ln_fold", 1))
+        del cfm, model
+        torch.cuda.empty_cache()
+    n_ref = cond.shape[1]
+    gen = lambda t: torch.cat([t[0, n_ref:1024], t[1, n_ref:870]])
+    e_fold, e_pass = rel_l2(gen(outs["fold"]), gen(outs["fp32"])), rel_l2(gen(outs["passes"]), gen(outs["fp32"]))
+    print(f"vs fp32 mode: LayerNorm fold {e_fold:.3e}, LayerNorm passes {e_pass:.3e}; fold vs passes {rel_l2(gen(outs['fold']), gen(outs['passes'])):.3e}")
+    assert e_fold < 2e-2 and e_fold < 1.25 * e_pass
+
+
 def test_bench_path_equal_durations_full_batch_against_fp32_mode():
     """The exact path `bench.py` times at C2: 32 utterances x 1024 frames, ALL durations equal, so CFM.sample asks for the unmasked kernels
     (attn_wide_kernel<false>, mask-free GEMM epilogues, persistent 256 x 256 tiles at 65 536 token rows), bf16, hipGraph replay.  Utterances
