@@ -56,6 +56,43 @@ int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, const float
     const bool lnf = rmw && g_ln_fold && ft && p->lnf_stats && p->fold_eval >= 0 && p->fold_eval < (int)ft->tv.size() && p->gemm_kernel != 0 &&
                      (p->gemm_kernel == 1 || rows >= 512) && D % 64 == 0 && inner % 64 == 0 && ff % 64 == 0;
     const size_t fR = (size_t)m->fold_R, frow0 = lnf ? ((size_t)p->fold_eval * c.depth) * fR : 0;
+    // LayerNorm sites of the folded evaluation, in order: k = 2l is block l's second LayerNorm (statistics: its out-projection), k = 2l - 1 its
+    // first (statistics: FF2 of block l - 1).  Site k's (mean, rstd) go to table k & 1; its pivots -- the rows' previous means -- are site k - 1's,
+    // in the other table (two tables: with the statistics taken inside the consumer kernel, sibling workgroups must still find the OLD means
+    // while feature tile 0's workgroups store the new ones).  A consumer launch on tiles narrower than 256 takes the statistics from the
+    // partial sums inside the kernel; the 256-wide tile needs them finalized by stats_finalize_kernel (same bits: lnf_stats_math.h).
+    float* const lnfS[2] = {p->lnf_stats, p->lnf_stats2};
+    PrefetchSet pf1f_prev{{nullptr, nullptr, nullptr, nullptr}, {0u, 0u, 0u, 0u}};
+    bool ink_qkv = false, ink_ff1 = false;
+    if (lnf && g_ln_fold_inkernel && p->lnf_stats2) {
+        GemmParams t = gp_zero();
+        t.M = rows; t.K = D; t.lda = D; t.ldw = D;
+        const int tiles_m = (rows + 255) / 256, ncu = f5_cu_count();
+        const bool sv = inner % 256 == 0 && tiles_m * (2 * inner / 256) <= ncu && tiles_m * (3 * inner / 256) > ncu && tiles_m * (2 * inner / 256) >= 160;
+        t.N = sv ? 2 * inner : 3 * inner;
+        ink_qkv = gemm_fast_lnf_inkernel(t);
+        if (sv) {
+            t.N = inner;
+            ink_qkv = ink_qkv && gemm_fast_lnf_inkernel(t);
+        }
+        t.N = ff;
+        ink_ff1 = gemm_fast_lnf_inkernel(t);
+    }
+    // consumer side of site k: finalized statistics (one more launch, which also prefetches `pf`) or the in-kernel form
+    auto lnf_consumer = [&](GemmParams& g, int k, bool inkernel, int site, int tag, const PrefetchSet* pf) -> int {
+        const float* pivots = k > 0 ? lnfS[(k - 1) & 1] : nullptr;
+        if (!inkernel) {
+            F5_TRY(timed(p, site, st, [&] {
+                return launch_stats_finalize(p->lnf_partial, (int)p->rows_cap, D / 64, rows, D, pivots, lnfS[k & 1], sat, tag, st, pf);
+            }));
+            g.lnf_stats = lnfS[k & 1];
+        } else {
+            g.lnf_stats = lnfS[k & 1];  // (marks the launch as folded; read only by the 256-wide tile)
+            g.lnf_partial = p->lnf_partial; g.lnf_partial_ld = (int)p->rows_cap; g.lnf_ncols = D / 64;
+            g.lnf_pivot = pivots; g.lnf_stats_out = lnfS[k & 1]; g.lnf_sat = sat; g.lnf_sat_tag = tag;
+        }
+        return 0;
+    };
     for (int l = 0; l < c.depth; ++l) {
         const BlockW& b = m->blocks[l];
         const float* ml = modp + (size_t)l * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp (modules.py:312)
@@ -105,7 +142,8 @@ int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, const float
         g.rope = rg ? p->rope_exp : p->rope; g.rope_inner = inner; g.rope_heads = m->rope_heads;  // (ragged: row r of a half -> its position in its utterance)
         if (lnf1) {
             g.A = p->xres16; g.W = fW; g.bias = nullptr;
-            g.lnf_stats = p->lnf_stats; g.lnf_c1 = fc1; g.lnf_c2 = fc2;
+            g.lnf_c1 = fc1; g.lnf_c2 = fc2;
+            F5_TRY(lnf_consumer(g, 2 * l - 1, ink_qkv, F5_SITE_LN1, 1 | (l << 4), wpf ? &pf1f_prev : nullptr));
         }
         // Tile quantisation at small batches: the fused projection has 12 feature tiles per token tile; when the q|k part alone (8 tiles
         // per token tile) fills the CUs a whole number of times but q|k|v does not (M = 8192, 4 utterances x 1024 frames x CFG: 256 + 128
@@ -133,6 +171,7 @@ int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, const float
                 gv.bias = nullptr;
                 gv.lnf_c1 = fc1 + 2 * inner;
                 gv.lnf_c2 = fc2 + 2 * inner;
+                gv.lnf_stats_out = nullptr;  // (the q|k launch's feature tile 0 stores the new means)
             }
             gv.out_t = (char*)p->qkv + (size_t)2 * inner * f5_elem_size(P);
             gv.rope = nullptr;
@@ -178,15 +217,14 @@ int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, const float
             g.ldof = D;
             g.add2_f16 = 1;
         }
-        if (lnf) {  // partial row sums of the updated stream; pivot = the row's previous mean (none yet in block 0: the table is this evaluation's)
-            g.stats_out = p->lnf_partial; g.stats_ld = (int)p->rows_cap; g.stats_pivot = l > 0 ? p->lnf_stats : nullptr;
+        if (lnf) {  // partial row sums of the updated stream (site 2l); pivot = the row's previous mean (none yet at site 0: the tables are this evaluation's)
+            g.stats_out = p->lnf_partial; g.stats_ld = (int)p->rows_cap; g.stats_pivot = l > 0 ? lnfS[(2 * l - 1) & 1] : nullptr;
+            if (wpf && ink_ff1) {  // no statistics launch behind this one: the GEMM itself touches the weights of FF1 and FF2
+                g.pf_p[0] = pf2f.p[0]; g.pf_n[0] = pf2f.n[0]; g.pf_p[1] = pf2f.p[1]; g.pf_n[1] = pf2f.n[1];
+            }
         }
         F5_TRY(timed(p, F5_SITE_OUT, st, [&] { return run_gemm(p, g, GEMM_DENSE, rmw ? EPI_RESID : EPI_GATE_T, st); }));
         // x += y; n2 = LN(x) * (1 + scale_mlp) + shift_mlp
-        if (lnf) F5_TRY(timed(p, F5_SITE_LN2, st, [&] {
-            return launch_stats_finalize(p->lnf_partial, (int)p->rows_cap, D / 64, rows, D, l > 0 ? p->lnf_stats : nullptr, p->lnf_stats, sat, 2 | (l << 4), st,
-                                         wpf ? &pf2f : nullptr);
-        }));
         if (!lnf) F5_TRY(timed(p, F5_SITE_LN2, st, [&] {
             if (rmw)
                 return launch_layernorm_res(P, xin, 1, xout, 1, D, rows, D, nullptr, D, nullptr, 1, ml + 4 * D, ml + 3 * D, mod_bstride, N, 1, p->hT, D, st,
@@ -199,7 +237,8 @@ int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, const float
         g.bias = b.b_ff1; g.act = ACT_GELU_TANH; g.out_t = p->ffh; g.ldo = ff; g.site = 3;
         if (lnf) {
             g.A = p->xres16; g.W = fW + (size_t)3 * inner * D * 2; g.bias = nullptr;
-            g.lnf_stats = p->lnf_stats; g.lnf_c1 = fc1 + 3 * inner; g.lnf_c2 = fc2 + 3 * inner;
+            g.lnf_c1 = fc1 + 3 * inner; g.lnf_c2 = fc2 + 3 * inner;
+            F5_TRY(lnf_consumer(g, 2 * l, ink_ff1, F5_SITE_LN2, 2 | (l << 4), wpf ? &pf2f : nullptr));
         }
         F5_TRY(timed(p, F5_SITE_FF1, st, [&] { return run_gemm(p, g, GEMM_DENSE, EPI_STORE_T, st); }));
         // y = gate_mlp * ff(n2)  (modules.py:639)
@@ -213,14 +252,14 @@ int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, const float
             g.add2_f16 = 1;
         }
         const bool lnf_next = lnf && l + 1 < c.depth;  // (the final AdaLN pass reads the stream itself)
-        if (lnf_next) {
-            g.stats_out = p->lnf_partial; g.stats_ld = (int)p->rows_cap; g.stats_pivot = p->lnf_stats;
+        if (lnf_next) {  // site 2l + 1
+            g.stats_out = p->lnf_partial; g.stats_ld = (int)p->rows_cap; g.stats_pivot = lnfS[(2 * l) & 1];
+            if (wpf && ink_qkv) {  // (see the out-projection) the next block's q|k|v weights and its out-projection
+                g.pf_p[0] = pf1f.p[0]; g.pf_n[0] = pf1f.n[0]; g.pf_p[1] = pf1f.p[1]; g.pf_n[1] = pf1f.n[1];
+            }
         }
         F5_TRY(timed(p, F5_SITE_FF2, st, [&] { return run_gemm(p, g, GEMM_DENSE, rmw ? EPI_RESID : EPI_GATE_T, st); }));
-        if (lnf_next) F5_TRY(timed(p, F5_SITE_LN1, st, [&] {
-            return launch_stats_finalize(p->lnf_partial, (int)p->rows_cap, D / 64, rows, D, p->lnf_stats, p->lnf_stats, sat, 1 | ((l + 1) << 4), st,
-                                         wpf ? &pf1f : nullptr);
-        }));
+        pf1f_prev = pf1f;  // (what a statistics launch in front of the next block's QKV projection prefetches)
     }
     const float* mf = modp + (size_t)c.depth * 6 * D;  // final AdaLN: (scale, shift) (modules.py:333)
     // (no stage tap: the stream itself is not needed any more, so the last add is not written back)

@@ -9,6 +9,11 @@ int g_res_f16 = 1;   // tuning knob ("residual_f16"): bf16 production mode keeps
 int g_ln_defer = 1;  // tuning knob ("ln_defer"): write the residual stream once per DiT block (0 = after every LayerNorm pass)
 int g_resid_rmw = 1;  // tuning knob ("resid_rmw"): see dit_eval
 int g_ln_fold = 1;    // tuning knob ("ln_fold"): LayerNorm fold (dit_eval); 0 = the two LayerNorm passes per block of round 3
+int g_ln_fold_inkernel = 0;  // tuning knob ("ln_fold_inkernel"): 1 = folded projections on tiles narrower than 256 take their row statistics from the
+                             // partial sums INSIDE the kernel, no statistics launch in front (and the producers prefetch the weights).  Same bits
+                             // (tested), but measured slower where it applies -- 1 x 1024: 79.0 - 80.1 against 76.9 - 77.6 ms per sample(), 2 x 1024:
+                             // 107.8 - 108.6 against 105.5 - 105.9 ms (gpurun_out/r4h_*): the 16 partial loads per row sit in front of a
+                             // latency-bound main loop and cost more than the 44 small launches they replace.  Off.
 int g_sync_evals = 0;  // diagnostic knob ("sync_evals"): an eager sample() synchronises the stream after every network evaluation, which bounds the
                        // number of dispatches in flight (profiles/r3_rocprof_pmc_sigsegv.md: rocprofv3 --pmc died under ~5 400 queued dispatches)
 

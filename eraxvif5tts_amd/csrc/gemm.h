@@ -61,6 +61,21 @@ struct GemmParams {
     const float* lnf_stats;  // [M][2] = (mean, rstd) of every token row of A, or null (no fold)
     const float* lnf_c1;     // [N] row sums of W'
     const float* lnf_c2;     // [N] bias + W . shift
+    // ... or, for every tile but the 256-wide one, the statistics are taken from the producer's partial sums INSIDE this kernel (no statistics
+    // launch in front: small launches are bound by launch count): lnf_partial[c * lnf_partial_ld + m] = float2 partial of feature tile c,
+    // lnf_ncols of them, added in the order c = 0, 1, ... exactly as stats_finalize_kernel adds them (lnf_stats_math.h: same bits); lnf_pivot
+    // [M][2] (column 0) or null; the workgroups of feature tile 0 also store (mean, rstd) to lnf_stats_out [M][2] (the next producer's pivots)
+    // and carry the fp16 range guard (lnf_sat / lnf_sat_tag).  gemm_fast_lnf_inkernel() tells the caller which form a launch can take.
+    const float* lnf_partial;
+    int lnf_partial_ld, lnf_ncols;
+    const float* lnf_pivot;
+    float* lnf_stats_out;
+    unsigned* lnf_sat;
+    int lnf_sat_tag;
+    // weights of the launches BEHIND this one, touched one dword per 128-byte line by the first threads of the grid (small launches are bound
+    // by the latency of weights that every block reads from HBM again; until round 4 the LayerNorm passes did this)
+    const void* pf_p[2];
+    unsigned pf_n[2];
     // LayerNorm fold, producer side (EPI_RESID on the fp16 stream, tuned kernel only): per token row and 64-feature wave tile the partial sums
     // (sum (h - pivot), sum (h - pivot)^2) over the fp16-ROUNDED values just stored: stats_out[(n / 64) * stats_ld + m] as float2, or null
     float* stats_out;
@@ -76,6 +91,10 @@ struct GemmParams {
 int launch_gemm(const GemmParams& p, int precision, int mode, int epi, int kernel_kind, hipStream_t stream);
 // true when the tuned kernel can run this problem (bf16, tile-multiple shapes, supported epilogue)
 bool gemm_fast_supported(const GemmParams& p, int precision, int mode, int epi);
+// the token x feature tile launch_gemm_fast would pick for this dense problem (by occupancy and the tuning knobs)
+void gemm_fast_tile(const GemmParams& p, int* bm, int* bn);
+// LayerNorm fold: true when a launch of this shape can take its row statistics from the partial sums inside the kernel (every tile but 256 x 256)
+bool gemm_fast_lnf_inkernel(const GemmParams& p);
 // dedicated kernel for the dim-1024 grouped Conv1d(k = 31) of ConvPositionEmbedding (conv31.hip); GemmParams as for GEMM_CONV31
 bool conv31_supported(const GemmParams& p, int precision, int epi);
 int launch_conv31(const GemmParams& p, hipStream_t stream);

@@ -22,6 +22,7 @@
 //     the DMA source row is shifted by tap-15 and rows outside the utterance read a zero page.
 //   * rows >= M / features >= N are clamped on load and dropped in the epilogue, so no padding contract on the caller.
 #include "gemm_tile.h"
+#include "lnf_stats_math.h"
 
 // This file is compiled as TWO translation units (build time): gemm_fast.hip itself holds every instantiation without the LayerNorm fold,
 // gemm_fast_lnf.hip (#define F5_LNF_TU + #include of this file) the LNF ones behind launch_gemm_fast_lnf().
@@ -60,7 +61,21 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
             p.clk[(size_t)blockIdx.x * 4 + 1] = r0;
         }
     }
+    // weight prefetch for the launches behind this one (GemmParams::pf_p): thread t of workgroup b touches line 512 b + t of each range; the
+    // loads are the oldest entries of the vector-memory queue (they retire before any operand piece) and their value is only looked at after
+    // the epilogue
+    [[maybe_unused]] unsigned pf0 = 0u, pf1 = 0u;  // (two registers, no arithmetic before the end: an xor here would wait for the loads)
+    if constexpr (VAR != 30) {                     // (small launches only; the persistent builds have no register to spare)
+        if (p.pf_n[0] | p.pf_n[1]) {
+            const size_t line = (size_t)blockIdx.x * 512u + tid;
+            if (line * 128u < p.pf_n[0]) pf0 = *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.pf_p[0]) + line * 128u);
+            if (line * 128u < p.pf_n[1]) pf1 = *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.pf_p[1]) + line * 128u);
+        }
+    }
     auto clk_end = [&]() {
+        if constexpr (VAR != 30) {
+            if ((pf0 ^ pf1) == 0x7fc0dead && (p.pf_n[0] | p.pf_n[1]) == 0xffffffffu) p.clk[0] = pf0;  // (never true: keeps the prefetch loads alive)
+        }
         if (p.clk) {
             const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
             if (tid == 0) {
@@ -208,6 +223,55 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
         const f32x2 st = *reinterpret_cast<const f32x2*>(lnf_lds + 512 + (j * 16 + fr) * 8);
         return epi_lnf4(a, st[0], st[1], c1, c2);
     };
+    // LayerNorm fold, statistics inside the kernel (gemm.h: lnf_partial): called behind the first operand requests, so that the partial sums'
+    // loads fly with them (in front of them they put one whole memory latency on the critical path of a latency-bound launch)
+    [[maybe_unused]] auto lnf_inkernel_stats = [&]() {
+        if constexpr (LNF && !LNF_LDS) {
+            if (p.lnf_partial) {
+                // statistics inside the kernel: the lnf_ncols partial sums of each of this lane's rows, added in stats_finalize_kernel's order
+                    // (the four lanes that share a row load the same addresses); issued before the main loop, behind the first operand fetch
+                    bool bad = false;
+                    float worst = 0.f;
+                    int worst_row = 0;
+#pragma unroll
+                    for (int j = 0; j < WM / 16; ++j) {
+                        int m = m0 + wm * WM + j * 16 + fr;
+                        const bool okrow = m < p.M;
+                        m = okrow ? m : p.M - 1;
+                        float s1 = 0.f, s2 = 0.f;
+                        if (p.lnf_ncols == 16) {  // dim 1024: all sixteen loads of a row in flight together (a runtime loop issues them one behind the other)
+                            f32x2 v[16];
+#pragma unroll
+                            for (int c = 0; c < 16; ++c) v[c] = *reinterpret_cast<const f32x2*>(p.lnf_partial + ((size_t)c * p.lnf_partial_ld + m) * 2);
+#pragma unroll
+                            for (int c = 0; c < 16; ++c) {
+                                s1 += v[c][0];
+                                s2 += v[c][1];
+                            }
+                        } else {
+                            for (int c = 0; c < p.lnf_ncols; ++c) {
+                                const f32x2 v = *reinterpret_cast<const f32x2*>(p.lnf_partial + ((size_t)c * p.lnf_partial_ld + m) * 2);
+                                s1 += v[0];
+                                s2 += v[1];
+                            }
+                        }
+                        const float pv = p.lnf_pivot ? p.lnf_pivot[(size_t)m * 2] : 0.0f;
+                        float mean, rstd, sumsq;
+                        lnf_row_stats(s1, s2, pv, p.K, mean, rstd, sumsq);
+                        lstr[j] = f32x2{mean, rstd};
+                        if (p.lnf_stats_out && n0 == 0 && wn == 0 && fq == 0 && okrow) {  // feature tile 0: the next producer's pivots, the range guard
+                            *reinterpret_cast<f32x2*>(p.lnf_stats_out + (size_t)m * 2) = lstr[j];
+                            if (!(sumsq < 65504.0f * 65504.0f)) {
+                                bad = true;
+                                worst = sumsq;
+                                worst_row = m;
+                            }
+                        }
+                    }
+                    if (p.lnf_stats_out && n0 == 0 && wn == 0) lnf_raise_guard(p.lnf_sat, bad, worst, p.lnf_sat_tag, worst_row + p.row0);
+            }
+        }
+    };
     auto prep_epilogue = [&]() {
         if constexpr (EPI == EPI_GATE_T || EPI == EPI_RESID) {
             const int mw = m0 + wm * WM;
@@ -240,11 +304,13 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
                 c1r[i] = *reinterpret_cast<const f32x4*>(p.lnf_c1 + ncol[i]);
                 c2r[i] = *reinterpret_cast<const f32x4*>(p.lnf_c2 + ncol[i]);
             }
+            if (!p.lnf_partial) {
 #pragma unroll
-            for (int j = 0; j < WM / 16; ++j) {
-                int m = m0 + wm * WM + j * 16 + fr;
-                m = m < p.M ? m : p.M - 1;
-                lstr[j] = *reinterpret_cast<const f32x2*>(p.lnf_stats + (size_t)m * 2);
+                for (int j = 0; j < WM / 16; ++j) {
+                    int m = m0 + wm * WM + j * 16 + fr;
+                    m = m < p.M ? m : p.M - 1;
+                    lstr[j] = *reinterpret_cast<const f32x2*>(p.lnf_stats + (size_t)m * 2);
+                }
             }
         }
     };
@@ -822,6 +888,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (d < nk) issue(d);
+    lnf_inkernel_stats();
     init_acc();
     wait_pieces(min(D - 1, nk - 1));  // K-step 0 has landed for this wave
     __builtin_amdgcn_s_barrier();     // ... and for every wave
@@ -958,6 +1025,10 @@ template <int BN, int WM, int MODE, int EPI, bool LNF = false> static int launch
             if (p.lnf_stats) pt.lnf_stats = p.lnf_stats + (size_t)mw * 2;
             if (p.stats_out) pt.stats_out = p.stats_out + (size_t)mw * 2;
             if (p.stats_pivot) pt.stats_pivot = p.stats_pivot + (size_t)mw * 2;
+            if (p.lnf_partial) pt.lnf_partial = p.lnf_partial + (size_t)mw * 2;
+            if (p.lnf_pivot) pt.lnf_pivot = p.lnf_pivot + (size_t)mw * 2;
+            if (p.lnf_stats_out) pt.lnf_stats_out = p.lnf_stats_out + (size_t)mw * 2;
+            pw.pf_n[0] = pw.pf_n[1] = 0u;
             F5_TRY((launch_fast<BN, WM, MODE, EPI, LNF>(pw, stream)));
             return launch_fast<128, 64, MODE, EPI, LNF>(pt, stream);
         }
@@ -1000,13 +1071,7 @@ bool gemm_fast_supported(const GemmParams& p, int precision, int mode, int epi) 
     return false;
 }
 
-int launch_gemm_fast(const GemmParams& p, int mode, int epi, hipStream_t stream) {
-    if (mode == GEMM_CONV31) {
-        if (conv31_supported(p, F5_PREC_BF16, epi)) return launch_conv31(p, stream);
-        if (epi == EPI_STORE_T) return launch_fast<64, 32, GEMM_CONV31, EPI_STORE_T>(p, stream);
-        if (epi == EPI_GATE_T) return launch_fast<64, 32, GEMM_CONV31, EPI_GATE_T>(p, stream);
-        return f5_fail(F5_EINVAL, "gemm_fast(conv31): unsupported epilogue %d", epi);
-    }
+void gemm_fast_tile(const GemmParams& p, int* pbm, int* pbn) {
     // tile width by occupancy: the 256-wide tile is the efficient one, narrower tiles keep the 256 CUs busy when the token count
     // is small (single-utterance serving: M = 2 x frames)
     const int tiles_m = cdiv(p.M, 256);
@@ -1037,6 +1102,25 @@ int launch_gemm_fast(const GemmParams& p, int mode, int epi, hipStream_t stream)
             bn = fbn;
         }
     }
+    *pbm = bm;
+    *pbn = bn;
+}
+
+bool gemm_fast_lnf_inkernel(const GemmParams& p) {
+    int bm, bn;
+    gemm_fast_tile(p, &bm, &bn);
+    return bn != 256;  // (the 256-wide tile stages finalized statistics through LDS; every other tile holds them in registers)
+}
+
+int launch_gemm_fast(const GemmParams& p, int mode, int epi, hipStream_t stream) {
+    if (mode == GEMM_CONV31) {
+        if (conv31_supported(p, F5_PREC_BF16, epi)) return launch_conv31(p, stream);
+        if (epi == EPI_STORE_T) return launch_fast<64, 32, GEMM_CONV31, EPI_STORE_T>(p, stream);
+        if (epi == EPI_GATE_T) return launch_fast<64, 32, GEMM_CONV31, EPI_GATE_T>(p, stream);
+        return f5_fail(F5_EINVAL, "gemm_fast(conv31): unsupported epilogue %d", epi);
+    }
+    int bn, bm;
+    gemm_fast_tile(p, &bm, &bn);
     if (p.lnf_stats) {  // LayerNorm fold: fp16 operands, statistics + column constants in the epilogue (QKV + RoPE, FF1 + GELU)
         if (!p.lnf_c1 || !p.lnf_c2 || (epi != EPI_STORE_T && epi != EPI_ROPE_T)) return f5_fail(F5_EINVAL, "gemm_fast: LayerNorm fold needs c1, c2 and a store / RoPE epilogue");
         return launch_gemm_fast_lnf(p, epi, bm, bn, stream);
@@ -1063,6 +1147,7 @@ int launch_gemm_fast(const GemmParams& p, int mode, int epi, hipStream_t stream)
 }
 #else  // F5_LNF_TU
 int launch_gemm_fast_lnf(const GemmParams& p, int epi, int bm, int bn, hipStream_t stream) {
+    if (bn == 256 && p.lnf_partial) return f5_fail(F5_ESTATE, "gemm_fast: the 256-wide LayerNorm-fold tile takes finalized statistics (gemm_fast_lnf_inkernel)");
 #define F5_FAST_LNF(E)                                                                           \
     if (epi == E) {                                                                              \
         if (bm == 128 && bn == 128) return launch_fast<128, 32, GEMM_DENSE, E, true>(p, stream); \

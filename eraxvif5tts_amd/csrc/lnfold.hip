@@ -12,6 +12,7 @@
 //                           element stored at the saturation value does that -- or is not a number raises the plan's flag words.
 #include "common.h"
 #include "kernels.h"
+#include "lnf_stats_math.h"
 
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -108,27 +109,13 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const f32x2_t* __re
             }
         }
         const float pv = pivot ? pivot[(size_t)row * 2] : 0.0f;
-        const float inv = 1.0f / (float)D;
-        const float md = s1 * inv;  // mean - pivot
-        float var = __builtin_fmaf(-md, md, s2 * inv);
-        var = var > 0.f ? var : 0.f;
-        stats[(size_t)row * 2] = pv + md;
-        stats[(size_t)row * 2 + 1] = 1.0f / sqrtf(var + 1e-6f);
-        // sum of squares of the stored elements themselves (not about the pivot): s2 + 2 pv s1 + D pv^2
-        sumsq = __builtin_fmaf(pv, __builtin_fmaf(2.0f, s1, (float)D * pv), s2);
+        float mean, rstd;
+        lnf_row_stats(s1, s2, pv, D, mean, rstd, sumsq);
+        stats[(size_t)row * 2] = mean;
+        stats[(size_t)row * 2 + 1] = rstd;
         bad = !(sumsq < 65504.0f * 65504.0f);
     }
-    if (sat && __builtin_amdgcn_ballot_w64(bad) != 0ull) {  // rare: same flag words as res_range_guard (elementwise.hip)
-        if (bad) {
-            const float bound = sqrtf(sumsq);  // an upper bound of the row's largest |element|
-            if (bound == bound && bound < 3.0e38f) atomicMax(sat + 1, __float_as_uint(bound));
-            if (!(sumsq == sumsq)) __hip_atomic_store(sat + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(sat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            atomicOr(sat + 3, 1u << (sat_tag & 15));
-            atomicOr(sat + 4, 1u << ((sat_tag >> 4) & 31));
-            atomicMax(sat + 5, 0x7fffffffu - (unsigned)row);
-        }
-    }
+    lnf_raise_guard(sat, bad, sumsq, sat_tag, row);
 }
 
 int launch_stats_finalize(const float* partial, int ld, int ncols, int rows, int D, const float* pivot, float* stats, unsigned* sat, int sat_tag,

@@ -157,6 +157,30 @@ def test_layernorm_fold_against_the_unfolded_path_and_fp32_mode():
     assert e_fold < 2e-2 and e_fold < 1.25 * e_pass
 
 
+def test_in_kernel_row_statistics_equal_the_statistics_kernel():
+    """The LayerNorm fold's consumers on tiles narrower than 256 can take (mean, rstd) from the producer's partial sums inside the kernel (knob
+    ln_fold_inkernel = 1; off by default: measured slower) instead of from stats_finalize_kernel: the two forms share lnf_stats_math.h and the
+    summation order, so a single-utterance sample() -- the shape that would take the in-kernel form -- must not change by one bit."""
+    import bench
+    from eraxvif5tts_amd import _lib
+    from eraxvif5tts_amd.model import CFM, DiT
+    lib = _lib.load()
+    torch.manual_seed(4321)
+    model = bench.synth_weights(DiT(**bench.BASE_ARCH, text_num_embeds=bench.VOCAB, mel_dim=100, precision="bf16"), seed=0)
+    cfm = CFM(transformer=model, mel_spec_kwargs={"mel_spec_type": "vocos"}).cuda()
+    cond, text, lens, dur = bench.synth_batch(1, 600, "cuda", seed=23)
+    y0 = torch.randn(1, 600, 100, generator=torch.Generator().manual_seed(24))
+    kw = dict(cond=cond, text=text, duration=dur, lens=lens, steps=2, cfg_strength=2.0, sway_sampling_coef=-1.0, y0=y0, return_trajectory=False, use_graph=False)
+    outs = []
+    for ink in (0, 1):
+        _lib.check(lib.f5_tuning_set(b"ln_fold_inkernel", ink))
+        try:
+            outs.append(cfm.sample(**kw)[0].cpu())
+        finally:
+            _lib.check(lib.f5_tuning_set(b"ln_fold_inkernel", 0))
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+
+
 def test_bench_path_equal_durations_full_batch_against_fp32_mode():
     """The exact path `bench.py` times at C2: 32 utterances x 1024 frames, ALL durations equal, so CFM.sample asks for the unmasked kernels
     (attn_wide_kernel<false>, mask-free GEMM epilogues, persistent 256 x 256 tiles at 65 536 token rows), bf16, hipGraph replay.  Utterances
