@@ -52,6 +52,12 @@ int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, const float
     // itself against this evaluation time's W' = fp16(W (1 + scale)), applying rstd (acc - mean c1) + c2 in their epilogues.  Block 0's first
     // pass stays (it folds the position-conv branch in), and so does the final AdaLN pass in front of proj_out.  Needs the in-place stream
     // (rmw), the time grid's table (stage_time_grid) and the tuned kernel at all four call sites.
+    // Token counts that are not a multiple of the 256-row tile (8 x 1001 frames, every ragged batch): the four block GEMMs run over the rows
+    // ROUNDED UP to 256 -- the workspace is padded to that anyway -- so that they stay on the persistent schedule with whole tiles only.  The rows
+    // past the last token compute on whatever the padding holds (finite: zero-filled arena, saturating fp16 stores) and nobody reads them:
+    // every other kernel works on `rows`, attention on the utterances' own rows.  (Round 4 first split such launches into whole tiles + a tail
+    // launch: 8 x 1001 346 against 288 ms per sample(), the ragged 4-chunk batch 210 against 183 ms -- the tail launches are pure latency.)
+    const int rows_g = (rmw && g_gemm_pad_rows && rows >= 3584 /* from here on the fused projection takes the 256-wide persistent tile */ && rows % 256 != 0 && (size_t)((rows + 255) / 256 * 256) <= p->rows_cap) ? (rows + 255) / 256 * 256 : rows;
     const FoldTable* ft = p->fold;
     const bool lnf = rmw && g_ln_fold && ft && p->lnf_stats && p->fold_eval >= 0 && p->fold_eval < (int)ft->tv.size() && p->gemm_kernel != 0 &&
                      (p->gemm_kernel == 1 || rows >= 512) && D % 64 == 0 && inner % 64 == 0 && ff % 64 == 0;
@@ -137,7 +143,7 @@ int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, const float
         if (l > 0) F5_TRY(tap_f32(p, "blk" + std::to_string(l - 1) + ".out", p->xres, D, rows, D, st));
         F5_TRY(tap_t(p, tn + ".n1", p->hT, D, rows, D, st));
         g = gp_zero();
-        g.A = p->hT; g.lda = D; g.W = b.w_qkv; g.ldw = D; g.M = rows; g.N = 3 * inner; g.K = D;
+        g.A = p->hT; g.lda = D; g.W = b.w_qkv; g.ldw = D; g.M = rows_g; g.N = 3 * inner; g.K = D;
         g.bias = b.b_qkv; g.out_t = p->qkv; g.ldo = 3 * inner; g.rows_per_batch = N; g.site = 1;
         g.rope = rg ? p->rope_exp : p->rope; g.rope_inner = inner; g.rope_heads = m->rope_heads;  // (ragged: row r of a half -> its position in its utterance)
         if (lnf1) {
@@ -207,7 +213,7 @@ int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, const float
         }
         // y = gate_msa * to_out(attn), 0 on padded query rows (modules.py:499-501, 635)
         g = gp_zero();
-        g.A = p->cT; g.lda = inner; g.W = b.w_o; g.ldw = inner; g.M = rows; g.N = D; g.K = inner;
+        g.A = p->cT; g.lda = inner; g.W = b.w_o; g.ldw = inner; g.M = rows_g; g.N = D; g.K = inner;
         g.bias = b.b_o; g.out_t = defer ? p->yA : p->yT; g.ldo = D; g.gate = ml + 2 * D; g.gate_bstride = mod_bstride; g.rows_per_batch = N;
         g.rowmask = mask; g.site = 2;
         g.rowbits = (mask && mask == p->rowbits_src) ? p->rowbits : nullptr;
@@ -233,7 +239,7 @@ int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, const float
                                         mod_bstride, N, 1, p->hT, D, st, wpf ? &pf2 : nullptr, sat, 2 | (l << 4));
         }));
         g = gp_zero();
-        g.A = p->hT; g.lda = D; g.W = b.w_ff1; g.ldw = D; g.M = rows; g.N = ff; g.K = D;
+        g.A = p->hT; g.lda = D; g.W = b.w_ff1; g.ldw = D; g.M = rows_g; g.N = ff; g.K = D;
         g.bias = b.b_ff1; g.act = ACT_GELU_TANH; g.out_t = p->ffh; g.ldo = ff; g.site = 3;
         if (lnf) {
             g.A = p->xres16; g.W = fW + (size_t)3 * inner * D * 2; g.bias = nullptr;
@@ -243,7 +249,7 @@ int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, const float
         F5_TRY(timed(p, F5_SITE_FF1, st, [&] { return run_gemm(p, g, GEMM_DENSE, EPI_STORE_T, st); }));
         // y = gate_mlp * ff(n2)  (modules.py:639)
         g = gp_zero();
-        g.A = p->ffh; g.lda = ff; g.W = b.w_ff2; g.ldw = ff; g.M = rows; g.N = D; g.K = ff;
+        g.A = p->ffh; g.lda = ff; g.W = b.w_ff2; g.ldw = ff; g.M = rows_g; g.N = D; g.K = ff;
         g.bias = b.b_ff2; g.out_t = p->yT; g.ldo = D; g.gate = ml + 5 * D; g.gate_bstride = mod_bstride; g.rows_per_batch = N; g.site = 4;
         if (rmw) {
             g.out_t = nullptr;

@@ -968,7 +968,7 @@ int g_gemm_group_sites = 0;  // diagnostic knob ("gemm_group_sites"): patch heig
 int g_gemm_tile = 0;   // diagnostic knob ("gemm_tile"): bm * 1000 + bn forces the tile of every tuned-GEMM launch that supports it (0 = by shape)
 int g_gemm_bm128 = 1;  // tuning knob ("gemm_bm128"): 128-row token tiles when the 256-row ones leave CUs without a workgroup (single-utterance launches)
 int g_gemm_lean = 1;   // tuning knob ("gemm_lean"): 1 = lean epilogue on whole tiles, 0 = generic epilogue everywhere
-int g_gemm_split_tail = 1;  // tuning knob ("gemm_split_tail"): 1 = M % 256 != 0 launches run as persistent whole tiles + a tail launch, 0 = one non-persistent launch
+int g_gemm_split_tail = 0;  // tuning knob ("gemm_split_tail"): 1 = M % 256 != 0 launches run as persistent whole tiles + a tail launch.  Measured a LOSS (the tail launch is pure latency: 8 x 1001 346 vs 288 ms); off.  dit_eval rounds the rows up instead ("gemm_pad_rows")
 
 static int persist_grid() { return gemm_persist_grid(); }
 #endif

@@ -475,7 +475,7 @@ extern "C" int f5_plan_create(f5_model_t m, int max_batch, int max_seq, int max_
         if ((rc = A.alloc_t(&p->grn_scratch, (size_t)max_batch * 2 * td + max_batch))) break;
         if ((rc = A.alloc_t(&p->filler, bn))) break;
         if ((rc = A.alloc_t(&p->mask, 2 * bn))) break;
-        if ((rc = A.alloc_t(&p->rowbits, (size_t)(2 * bn / 128 + 1) * 16))) break;
+        if ((rc = A.alloc_t(&p->rowbits, (size_t)(2 * bn / 128 + 4) * 16))) break;  // (+ the padded rows of a launch rounded up to 256)
         if ((rc = A.alloc_t(&p->traj, (size_t)(max_evals + 1) * bn * mel))) break;
         if ((rc = A.alloc_t(&p->xmid, bn * mel))) break;
         if ((rc = A.alloc_t(&p->cond_in, bn * mel))) break;

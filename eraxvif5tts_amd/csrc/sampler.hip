@@ -105,7 +105,7 @@ static int run_sample_loop(f5_plan_s* p, const SampleArgs& a, int use_graph, hip
                 (void)hipGraphDestroy(g.graph);
                 return f5_fail(F5_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
             }
-            if (p->graphs.size() >= 8) {  // small LRU-less cache: drop the oldest bucket
+            if (p->graphs.size() >= 32) {  // small LRU-less cache: drop the oldest bucket (32: batch inference over length buckets meets a few dozen shapes)
                 (void)hipGraphExecDestroy(p->graphs[0].exec);
                 (void)hipGraphDestroy(p->graphs[0].graph);
                 p->graphs.erase(p->graphs.begin());

@@ -201,6 +201,12 @@ class DiT(nn.Module):
                 self._finish_plan(h)  # a deferred sample() still owns this plan's staged inputs and flag words: complete it first
                 return h
         lib = _lib.load()
+        # no plan of this stream fits: the new one covers the old ones' shapes too (elementwise maximum), so that a caller that alternates between
+        # shapes -- batch inference over length buckets: few long or many short utterances -- converges on ONE plan per stream instead of
+        # allocating and freeing gigabytes (and dropping captured graphs) at every change of bucket
+        for (st_, b, n, e), _h in self._plans:
+            if st_ == stream:
+                batch, seq, evals = max(batch, b), max(seq, n), max(evals, e)
         seq_cap = min(4096, -(-seq // 64) * 64)
         h = C.c_void_p()
         _lib.check(lib.f5_plan_create(self.native(), batch, seq_cap, max(evals, 1), C.byref(h)), "plan_create")

@@ -1,6 +1,8 @@
 """HBM-side traffic per launch of every hot kernel IN SITU: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate passes, counters
 only) over one eager two-step C2 sample() (tools/sample_one.py), averaged per kernel name.  FETCH_SIZE reads 1/2 on gfx950 (MI355X_MICROARCH.md).
-   python tools/pmc_insitu_traffic.py collect <outdir> [bench args...]     python tools/pmc_insitu_traffic.py summarise <outdir>"""
+   python tools/pmc_insitu_traffic.py collect <outdir> [bench args...]     python tools/pmc_insitu_traffic.py summarise <outdir> [qkv_traffic.json]
+With a json path, the in-situ figure of the fused QKV projection (round 4: the LayerNorm-fold build gemm_fast_kernel<256, 128, 0, 4, 30, 5, true>) is
+written in the form bench.py reads for roofline.traffic."""
 import collections
 import csv
 import glob
@@ -23,7 +25,7 @@ def collect(outdir, extra):
             sys.exit(1)
 
 
-def summarise(outdir):
+def summarise(outdir, json_out=None):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -38,12 +40,24 @@ def summarise(outdir):
         rows.append((fetch + write, k, n, fetch, write))
     rows.sort(reverse=True)
     print(f"{'kernel':<70s} {'launches':>8s} {'fetch MB':>10s} {'write MB':>10s} {'total MB':>10s}   (per launch, HBM side of L2)")
-    for tot, k, n, fetch, write in rows[:16]:
+    for tot, k, n, fetch, write in rows[:18]:
         print(f"{k[:70]:<70s} {n:8d} {fetch / 1e6:10.1f} {write / 1e6:10.1f} {tot / 1e6:10.1f}")
+    if json_out:
+        import json
+        qkv = [r for r in rows if "gemm_fast_kernel<256, 128, 0, 4, 30, 5, true>" in r[1]] or [r for r in rows if "gemm_fast_kernel<256, 128, 0, 4, 30, 5" in r[1]]
+        if not qkv:
+            sys.exit("no fused-QKV launch of the persistent kernel in the counter files")
+        tot, k, n, fetch, write = qkv[0]
+        rec = {"qkv": {"rows": 65536, "seq_len": 1024, "bytes_per_launch": int(tot), "fetch_bytes": int(fetch), "write_bytes": int(write), "launches": n,
+                       "kernel": k, "algorithmic_bytes": 65536 * 1024 * 2 + 3072 * 1024 * 2 + 65536 * 3072 * 2 + 65536 * 8,
+                       "how": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (two separate passes) over one eager two-step C2 sample() (tools/sample_one.py), mean "
+                              "over the launches of the fused QKV + RoPE projection IN SITU; FETCH_SIZE x 2 (gfx950)"}}
+        with open(json_out, "w") as f:
+            json.dump(rec, f, indent=1)
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "collect":
         collect(sys.argv[2], sys.argv[3:])
     else:
-        summarise(sys.argv[2])
+        summarise(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
