@@ -370,27 +370,31 @@ def extra_workloads(args, dev, model, cfm):
     # pass of a shape captures its hipGraph, the third replays it).
     from eraxvif5tts_amd.eval import prompts as P
     meta = P.synthetic_metainfo(48, seed=1, min_secs=3.0, max_secs=20.0)
-    buckets = P.get_inference_prompt(meta, tokenizer="char", infer_batch_size=6000, num_buckets=40, min_secs=3, max_secs=40, device=dev)
-    frames = sum(sum(b[4]) for b in buckets)
-    padded_rows = sum(len(b[4]) * max(b[4]) for b in buckets)
-    bkw = dict(nfe_step=nfe, cfg_strength=args.cfg, sway_sampling_coef=-1.0, seed=0)
-    times = {}
-    for mode in ("padded", "ragged"):
-        for _pass in range(3):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            n_out = sum(1 for _ in P.infer_prompts(cfm, buckets, mode=mode, **bkw))
-            torch.cuda.synchronize()
-            times[mode] = time.perf_counter() - t0
-        assert n_out == len(meta)
-    out["bucketed_eval"] = {"value": round(frames / times["ragged"], 2), "unit": "mel-frames/s", "ms_per_step": round(times["ragged"] * 1e3, 3),
-                            "padded_value": round(frames / times["padded"], 2), "padded_ms": round(times["padded"] * 1e3, 3),
-                            "speedup_vs_padded": round(times["padded"] / times["ragged"], 3), "utterances": len(meta), "buckets": len(buckets),
-                            "frames": int(frames), "padded_rows": int(padded_rows),
-                            "config": f"48 synthetic utterances, total length U(3, 20) s, prompt U(2, 6) s, {len(buckets)} buckets of >= 6000 frames "
-                                      f"(utils_eval.get_inference_prompt), NFE={nfe} CFG={args.cfg:g} sway=-1, bf16; value = ragged sampler, "
-                                      "padded_value = the reference's padded + masked batches; hipGraph replay of recurring bucket shapes"}
-    del buckets, meta
+    # two bucketings of the same set: fine (40 length buckets, >= 6 000 frames per batch: batches of 2 - 6 utterances of nearly equal length, 2 % of the
+    # padded rows are padding) and coarse (4 buckets, >= 16 000 frames: bigger batches, mixed lengths -- where padding costs and the ragged form pays)
+    for key, nb, budget in (("bucketed_eval", 40, 6000), ("bucketed_eval_coarse", 4, 16000)):
+        buckets = P.get_inference_prompt(meta, tokenizer="char", infer_batch_size=budget, num_buckets=nb, min_secs=3, max_secs=40, device=dev)
+        frames = sum(sum(b[4]) for b in buckets)
+        padded_rows = sum(len(b[4]) * max(b[4]) for b in buckets)
+        bkw = dict(nfe_step=nfe, cfg_strength=args.cfg, sway_sampling_coef=-1.0, seed=0)
+        times = {}
+        for mode in ("padded", "ragged"):
+            for _pass in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                n_out = sum(1 for _ in P.infer_prompts(cfm, buckets, mode=mode, **bkw))
+                torch.cuda.synchronize()
+                times[mode] = time.perf_counter() - t0
+            assert n_out == len(meta)
+        out[key] = {"value": round(frames / times["ragged"], 2), "unit": "mel-frames/s", "ms_per_step": round(times["ragged"] * 1e3, 3),
+                    "padded_value": round(frames / times["padded"], 2), "padded_ms": round(times["padded"] * 1e3, 3),
+                    "speedup_vs_padded": round(times["padded"] / times["ragged"], 3), "utterances": len(meta), "buckets": len(buckets),
+                    "frames": int(frames), "padded_rows": int(padded_rows),
+                    "config": f"48 synthetic utterances, total length U(3, 20) s, prompt U(2, 6) s, {len(buckets)} batches from {nb} length buckets of >= {budget} "
+                              f"frames (utils_eval.get_inference_prompt), NFE={nfe} CFG={args.cfg:g} sway=-1, bf16; value = ragged sampler, padded_value = the "
+                              "reference's padded + masked batches; third pass of each (hipGraph replay of the recurring shapes)"}
+        del buckets
+    del meta
     torch.cuda.empty_cache()
     v = bench_vocos(args, dev, T=683, B=32, steps=20, warmup=3)
     out["C5"] = {"value": v["value"], "unit": v["unit"], "ms_per_step": v["ms_per_step"], "rtf": v["rtf"], "config": v["config"]["workload"],

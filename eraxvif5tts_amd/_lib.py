@@ -15,6 +15,7 @@ F5_ROPE_ADJACENT, F5_ROPE_HALF_SPLIT = 0, 1
 F5_BACKBONE_DIT, F5_BACKBONE_UNETT, F5_BACKBONE_MMDIT = 0, 1, 2
 F5_SKIP = {"concat": 0, "add": 1, "none": 2}
 SITES = ("qkv", "attention", "attn_out", "ff1", "ff2", "ln1", "ln2", "conv31", "input_proj")  # F5_SITE_* order
+F5_MEL_VOCOS, F5_MEL_BIGVGAN = 0, 1
 ACT = {"none": 0, "gelu_tanh": 1, "gelu_erf": 2, "mish": 3}
 
 
@@ -33,7 +34,7 @@ class VocosConfig(C.Structure):
 
 
 class MelConfig(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("n_fft", "hop", "win", "n_mels", "sample_rate")]
+    _fields_ = [(n, C.c_int32) for n in ("n_fft", "hop", "win", "n_mels", "sample_rate", "mel_type")]
 
 
 class DurationWeights(C.Structure):  # struct f5_duration_weights

@@ -34,21 +34,23 @@ struct f5_frontend_s {
 };
 
 // ----------------------------------------------------------------------------- kernels
-// frames[(b*T + t)][n] = wave[b][reflect(t*hop + n - n_fft/2)]   (torch.stft center=True, pad_mode="reflect")
-__global__ __launch_bounds__(256) void mel_frames_kernel(const float* __restrict__ wave, int nw, int T, int n_fft, int hop, float* __restrict__ frames,
+// frames[(b*T + t)][n] = wave[b][reflect(t*hop + n - pad)]: pad = n_fft / 2 for torch.stft(center=True, pad_mode="reflect") (vocos mel),
+// pad = (n_fft - hop) / 2 for the explicit reflect padding + center=False of get_bigvgan_mel_spectrogram (modules.py:51-52)
+__global__ __launch_bounds__(256) void mel_frames_kernel(const float* __restrict__ wave, int nw, int T, int n_fft, int hop, int pad, float* __restrict__ frames,
                                                          size_t total) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int n = (int)(i % n_fft);
     const size_t row = i / n_fft;
     const int t = (int)(row % T), b = (int)(row / T);
-    int s = t * hop + n - n_fft / 2;
+    int s = t * hop + n - pad;
     if (s < 0) s = -s;
     if (s >= nw) s = 2 * (nw - 1) - s;
     frames[i] = wave[(size_t)b * nw + s];
 }
-// mag[r][k] = sqrt(re^2 + im^2), zero in the padding columns F..Fp-1
-__global__ __launch_bounds__(256) void mel_magnitude_kernel(const float* __restrict__ spec, int lds, int F, int Fp, float* __restrict__ mag, size_t total) {
+// mag[r][k] = sqrt(re^2 + im^2 + eps) (eps = 0: torchaudio power = 1; 1e-9: modules.py:67), zero in the padding columns F..Fp-1
+__global__ __launch_bounds__(256) void mel_magnitude_kernel(const float* __restrict__ spec, int lds, int F, int Fp, float eps, float* __restrict__ mag,
+                                                            size_t total) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int k = (int)(i % Fp);
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(256) void mel_magnitude_kernel(const float* __restr
     float v = 0.f;
     if (k < F) {
         const float re = spec[r * lds + k], im = spec[r * lds + F + k];
-        v = sqrtf(re * re + im * im);
+        v = sqrtf(re * re + im * im + eps);
     }
     mag[i] = v;
 }
@@ -89,13 +91,23 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
 
 // ----------------------------------------------------------------------------- handle
 static double hz_to_mel_htk(double f) { return 2595.0 * log10(1.0 + f / 700.0); }
+// librosa.filters.mel (Slaney / Auditory-toolbox scale, htk = False): linear below 1 kHz (200 / 3 Hz per mel), logarithmic above (log(6.4) / 27 per mel)
+static double hz_to_mel_slaney(double f) {
+    const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
+    return f >= min_log_hz ? min_log_mel + log(f / min_log_hz) / logstep : f / f_sp;
+}
+static double mel_to_hz_slaney(double m) {
+    const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
+    return m >= min_log_mel ? min_log_hz * exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
 
 extern "C" int f5_frontend_create(const f5_mel_config* c, f5_frontend_t* out) {
     if (!c || !out) return f5_fail(F5_EINVAL, "null argument");
     *out = nullptr;
     F5_TRY(f5_check_device());
-    if (c->n_fft <= 0 || c->n_fft % 32 != 0 || c->hop <= 0 || c->win <= 0 || c->win > c->n_fft || c->n_mels <= 0 || c->sample_rate <= 0)
-        return f5_fail(F5_EINVAL, "bad mel config (n_fft a multiple of 32, win <= n_fft)");
+    if (c->n_fft <= 0 || c->n_fft % 32 != 0 || c->hop <= 0 || c->win <= 0 || c->win > c->n_fft || c->n_mels <= 0 || c->sample_rate <= 0 ||
+        (c->mel_type != F5_MEL_VOCOS && c->mel_type != F5_MEL_BIGVGAN) || (c->mel_type == F5_MEL_BIGVGAN && c->hop > c->n_fft))
+        return f5_fail(F5_EINVAL, "bad mel config (n_fft a multiple of 32, win <= n_fft, mel_type 0 | 1)");
     f5_frontend_s* h = new f5_frontend_s();
     h->cfg = *c;
     const int N = c->n_fft, F = N / 2 + 1, Fp = (int)round_up(F, 32);
@@ -114,7 +126,23 @@ extern "C" int f5_frontend_create(const f5_mel_config* c, f5_frontend_t* out) {
         }
     // torchaudio.functional.melscale_fbanks(norm=None, mel_scale="htk"), fp32 arithmetic as torch does it
     std::vector<float> fb((size_t)c->n_mels * Fp, 0.f);
-    {
+    if (c->mel_type == F5_MEL_BIGVGAN) {
+        // librosa.filters.mel(sr, n_fft, n_mels, fmin = 0, fmax = sr / 2, htk = False, norm = "slaney"), float64 arithmetic, float32 result: n_mels + 2
+        // band edges equally spaced on the Slaney mel scale, triangles max(0, min(lower, upper)) over the FFT bin frequencies, every filter
+        // scaled by 2 / (its band width in Hz) -- unit area.  (librosa is absent from the reference tree: restated from the published algorithm.)
+        const int M = c->n_mels;
+        std::vector<double> mel_f(M + 2);
+        const double m_min = hz_to_mel_slaney(0.0), m_max = hz_to_mel_slaney(c->sample_rate / 2.0);
+        for (int i = 0; i < M + 2; ++i) mel_f[i] = mel_to_hz_slaney(m_min + (m_max - m_min) * (double)i / (double)(M + 1));
+        for (int m = 0; m < M; ++m) {
+            const double enorm = 2.0 / (mel_f[m + 2] - mel_f[m]);
+            for (int k = 0; k < F; ++k) {
+                const double freq = (c->sample_rate / 2.0) * (double)k / (double)(F - 1);
+                const double lower = (freq - mel_f[m]) / (mel_f[m + 1] - mel_f[m]), upper = (mel_f[m + 2] - freq) / (mel_f[m + 2] - mel_f[m + 1]);
+                fb[(size_t)m * Fp + k] = (float)(std::max(0.0, std::min(lower, upper)) * enorm);
+            }
+        }
+    } else {
         const int M = c->n_mels;
         std::vector<float> f_pts(M + 2);
         const float m_min = (float)hz_to_mel_htk(0.0), m_max = (float)hz_to_mel_htk(c->sample_rate / 2.0);
@@ -152,9 +180,11 @@ extern "C" int f5_frontend_mel(f5_frontend_t h, int B, int nw, const float* wave
     if (!h || !wave || !mel || B <= 0) return f5_fail(F5_EINVAL, "bad argument");
     F5_TRY(f5_check_device());
     const f5_mel_config& c = h->cfg;
-    if (nw <= c.n_fft / 2) return f5_fail(F5_EINVAL, "mel: %d samples are too few for reflect padding of %d", nw, c.n_fft / 2);
+    const bool big = c.mel_type == F5_MEL_BIGVGAN;
+    const int pad = big ? (c.n_fft - c.hop) / 2 : c.n_fft / 2;
+    if (nw <= pad || (big && nw + 2 * pad < c.n_fft)) return f5_fail(F5_EINVAL, "mel: %d samples are too few for reflect padding of %d", nw, pad);
     hipStream_t st = (hipStream_t)stream;
-    const int N = c.n_fft, F = h->F, Fp = h->Fp, T = nw / c.hop + 1, M = c.n_mels;
+    const int N = c.n_fft, F = h->F, Fp = h->Fp, T = big ? (nw + 2 * pad - c.n_fft) / c.hop + 1 : nw / c.hop + 1, M = c.n_mels;
     const size_t rows = (size_t)B * T;
     if (rows > h->work_rows) {  // grow the workspace (the mel runs once per sample(); not a per-step allocation)
         F5_HIP(hipStreamSynchronize(st));
@@ -166,13 +196,13 @@ extern "C" int f5_frontend_mel(f5_frontend_t h, int B, int nw, const float* wave
         F5_TRY(h->work.alloc_t(&h->melT, rows * M, false));
         h->work_rows = rows;
     }
-    hipLaunchKernelGGL(mel_frames_kernel, dim3(blocks_of(rows * N)), dim3(256), 0, st, wave, nw, T, N, c.hop, h->frames, rows * N);
+    hipLaunchKernelGGL(mel_frames_kernel, dim3(blocks_of(rows * N)), dim3(256), 0, st, wave, nw, T, N, c.hop, pad, h->frames, rows * N);
     F5_LAUNCH_CHECK();
     GemmParams g;
     memset(&g, 0, sizeof(g));
     g.A = h->frames; g.lda = N; g.W = h->dft; g.ldw = N; g.M = (int)rows; g.N = 2 * F; g.K = N; g.out_f = h->spec; g.ldof = 2 * F;
     F5_TRY(launch_gemm(g, F5_PREC_FP32, GEMM_DENSE, EPI_STORE_F32, 0, st));
-    hipLaunchKernelGGL(mel_magnitude_kernel, dim3(blocks_of(rows * Fp)), dim3(256), 0, st, h->spec, 2 * F, F, Fp, h->mag, rows * Fp);
+    hipLaunchKernelGGL(mel_magnitude_kernel, dim3(blocks_of(rows * Fp)), dim3(256), 0, st, h->spec, 2 * F, F, Fp, big ? 1e-9f : 0.0f, h->mag, rows * Fp);
     F5_LAUNCH_CHECK();
     memset(&g, 0, sizeof(g));
     g.A = h->mag; g.lda = Fp; g.W = h->fb; g.ldw = Fp; g.M = (int)rows; g.N = M; g.K = Fp; g.out_f = h->melT; g.ldof = M;

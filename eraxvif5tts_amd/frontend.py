@@ -20,13 +20,13 @@ def _device_index(t: torch.Tensor) -> int:
     return t.device.index if t.device.index is not None else torch.cuda.current_device()
 
 
-def _handle(device_index, n_fft, hop, win, n_mels, sample_rate):
-    key = (device_index, n_fft, hop, win, n_mels, sample_rate)
+def _handle(device_index, n_fft, hop, win, n_mels, sample_rate, mel_type=_lib.F5_MEL_VOCOS):
+    key = (device_index, n_fft, hop, win, n_mels, sample_rate, mel_type)
     h = _handles.get(key)
     if h is None:
         _lib.require_gpu()
         lib = _lib.load()
-        cfg = _lib.MelConfig(n_fft=n_fft, hop=hop, win=win, n_mels=n_mels, sample_rate=sample_rate)
+        cfg = _lib.MelConfig(n_fft=n_fft, hop=hop, win=win, n_mels=n_mels, sample_rate=sample_rate, mel_type=mel_type)
         h = C.c_void_p()
         with torch.cuda.device(device_index):  # the handle's tables and workspace are allocated on the current device
             _lib.check(lib.f5_frontend_create(C.byref(cfg), C.byref(h)), "frontend_create")
@@ -48,15 +48,20 @@ def _destroy_handles():
 
 
 @torch.no_grad()
-def mel_spectrogram(wave: torch.Tensor, n_fft=1024, hop_length=256, win_length=1024, n_mel_channels=100, target_sample_rate=24000) -> torch.Tensor:
-    """wave [b, nw] on the GPU -> log-mel [b, n_mels, nw // hop + 1] (float32), all arithmetic in libf5hip."""
+def mel_spectrogram(wave: torch.Tensor, n_fft=1024, hop_length=256, win_length=1024, n_mel_channels=100, target_sample_rate=24000,
+                    mel_type="vocos") -> torch.Tensor:
+    """wave [b, nw] on the GPU -> log-mel (float32), all arithmetic in libf5hip.  mel_type "vocos": [b, n_mels, nw // hop + 1] (torchaudio
+    MelSpectrogram, reference modules.py:75-101); "bigvgan": [b, n_mels, (nw + 2 pad - n_fft) // hop + 1] with pad = (n_fft - hop) // 2
+    (get_bigvgan_mel_spectrogram, modules.py:29-72)."""
     lib = _lib.load()
     w = wave.to(dtype=torch.float32).contiguous()
     b, nw = w.shape
     dev = _device_index(w)
-    out = torch.empty(b, n_mel_channels, nw // hop_length + 1, device=w.device, dtype=torch.float32)
+    mt = {"vocos": _lib.F5_MEL_VOCOS, "bigvgan": _lib.F5_MEL_BIGVGAN}[mel_type]
+    frames = nw // hop_length + 1 if mt == _lib.F5_MEL_VOCOS else (nw + 2 * ((n_fft - hop_length) // 2) - n_fft) // hop_length + 1
+    out = torch.empty(b, n_mel_channels, frames, device=w.device, dtype=torch.float32)
     with torch.cuda.device(dev):
-        _lib.check(lib.f5_frontend_mel(_handle(dev, n_fft, hop_length, win_length, n_mel_channels, target_sample_rate), b, nw, _lib.ptr(w),
+        _lib.check(lib.f5_frontend_mel(_handle(dev, n_fft, hop_length, win_length, n_mel_channels, target_sample_rate, mt), b, nw, _lib.ptr(w),
                                        _lib.ptr(out), _lib.stream_ptr()), "frontend_mel")
     return out
 

@@ -308,7 +308,13 @@ typedef struct f5_mel_config {
     int32_t win;         /* 1024 (<= n_fft; centred) */
     int32_t n_mels;      /* 100 */
     int32_t sample_rate; /* 24000: the filterbank spans 0 .. sample_rate / 2 */
+    int32_t mel_type;    /* F5_MEL_VOCOS (0): torchaudio MelSpectrogram, HTK scale, center = True -> nw / hop + 1 frames (modules.py:75-101);
+                            F5_MEL_BIGVGAN (1, round 4): get_bigvgan_mel_spectrogram (modules.py:29-72): reflect padding of (n_fft - hop) / 2,
+                            center = False -> (nw + 2 pad - n_fft) / hop + 1 frames, sqrt(re^2 + im^2 + 1e-9), librosa's Slaney-scale
+                            area-normalised filterbank */
 } f5_mel_config;
+#define F5_MEL_VOCOS 0
+#define F5_MEL_BIGVGAN 1
 F5_API int f5_frontend_create(const f5_mel_config* cfg, f5_frontend_t* out);
 F5_API int f5_frontend_destroy(f5_frontend_t h);
 F5_API int f5_frontend_mel(f5_frontend_t h, int B, int nw, const float* wave, float* mel, f5_stream_t stream);

@@ -573,6 +573,48 @@ def mel_spectrogram(wave, n_fft=1024, hop=256, win=1024, n_mels=100, sr=24000):
     return mel.clamp(min=1e-5).log()  # [b, n_mels, nw//hop + 1]
 
 
+# ----------------------------------------------------------------------------- f4: the BigVGAN mel front-end (modules.py:29-72)
+def librosa_mel_filterbank(sr=24000, n_fft=1024, n_mels=100, fmin=0.0, fmax=None):
+    """librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax) with its defaults htk=False, norm="slaney" -- the call of modules.py:45 -- restated from
+    the published algorithm (librosa is absent from the reference tree: parity unpinned at this boundary): n_mels + 2 band edges equally spaced on
+    the Slaney / Auditory-toolbox mel scale (linear below 1 kHz at 200/3 Hz per mel, log above with log(6.4)/27 per mel), triangular weights over
+    the rfft bin frequencies, each filter scaled by 2 / (its band width in Hz).  float64 arithmetic, float32 result [n_mels, n_fft // 2 + 1]."""
+    import numpy as np
+    fmax = sr / 2.0 if fmax is None else fmax
+    f_sp, min_log_hz, logstep = 200.0 / 3.0, 1000.0, np.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+
+    def hz_to_mel(f):
+        f = np.asarray(f, dtype=np.float64)
+        return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-300) / min_log_hz) / logstep, f / f_sp)
+
+    def mel_to_hz(m):
+        m = np.asarray(m, dtype=np.float64)
+        return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+    fftfreqs = np.fft.rfftfreq(n=n_fft, d=1.0 / sr)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = np.subtract.outer(mel_f, fftfreqs)
+    weights = np.zeros((n_mels, 1 + n_fft // 2), dtype=np.float64)
+    for i in range(n_mels):
+        weights[i] = np.maximum(0, np.minimum(-ramps[i] / fdiff[i], ramps[i + 2] / fdiff[i + 1]))
+    weights *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return weights.astype(np.float32)
+
+
+def bigvgan_mel_spectrogram(wave, n_fft=1024, n_mels=100, sr=24000, hop=256, win=1024, fmin=0, fmax=None):
+    """modules.py:29-72 (get_bigvgan_mel_spectrogram): reflect padding of (n_fft - hop) / 2 on both sides, torch.stft(center=False, periodic Hann),
+    sqrt(re^2 + im^2 + 1e-9), the librosa filterbank, log(clamp(min=1e-5)).  wave [b, nw] -> [b, n_mels, (nw + 2 pad - n_fft) // hop + 1]."""
+    mel_basis = torch.from_numpy(librosa_mel_filterbank(sr, n_fft, n_mels, fmin, fmax)).float()
+    pad = (n_fft - hop) // 2
+    w = F.pad(wave.float().unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)
+    spec = torch.stft(w, n_fft, hop_length=hop, win_length=win, window=torch.hann_window(win), center=False, pad_mode="reflect", normalized=False,
+                      onesided=True, return_complex=True)
+    spec = torch.sqrt(torch.view_as_real(spec).pow(2).sum(-1) + 1e-9)
+    return torch.log(torch.clamp(torch.matmul(mel_basis, spec), min=1e-5))
+
+
 # ----------------------------------------------------------------------------- f3: sample-rate conversion (unpinned: torchaudio absent)
 def resample(wave, orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99):
     """torchaudio.transforms.Resample(orig, new) with its defaults (resampling_method "sinc_interp_hann", width 6, rolloff 0.99), the call

@@ -121,7 +121,11 @@ def load_reference():
     for name in ("torchaudio", "librosa", "jieba", "pypinyin"):
         _shell(name)
     lf = _shell("librosa.filters")
-    lf.mel = None
+
+    def _librosa_mel(sr, n_fft, n_mels=128, fmin=0.0, fmax=None, **_):  # librosa is absent: the oracle's restatement of its published algorithm
+        import cpu_ref
+        return cpu_ref.librosa_mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+    lf.mel = _librosa_mel
     sys.modules["librosa"].filters = lf
     sys.modules["pypinyin"].lazy_pinyin = None
     sys.modules["pypinyin"].Style = None

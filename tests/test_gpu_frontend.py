@@ -69,3 +69,20 @@ def test_resample_matches_oracle(orig, new):
     out = audio.resample(wav.cuda(), orig, new).cpu()  # device tensor: f5_frontend_resample
     assert out.shape == ref.shape == (2, math.ceil(new // math.gcd(orig, new) * n / (orig // math.gcd(orig, new))))
     assert rel_l2(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("nw", [24000, 7777, 2048])
+def test_bigvgan_mel_matches_oracle(nw):
+    """MelSpec(mel_spec_type="bigvgan") on the device (f5_frontend_mel with mel_type F5_MEL_BIGVGAN: reflect padding of (n_fft - hop) / 2, no centring,
+    sqrt(power + 1e-9), Slaney filterbank built in C++) against oracle/cpu_ref.bigvgan_mel_spectrogram, which is pinned to the reference's own
+    get_bigvgan_mel_spectrogram (tests/golden/bigvgan_mel.npz).  Same tolerance as the vocos mel: |d log-mel| <= 2e-3 above the floor."""
+    from eraxvif5tts_amd.model.modules import MelSpec
+    g = torch.Generator().manual_seed(nw)
+    t = torch.arange(nw) / 24000.0
+    wav = torch.stack([0.3 * torch.sin(2 * math.pi * 200 * t) * (1 + 0.4 * torch.sin(2 * math.pi * 4 * t)) + 0.02 * torch.randn(nw, generator=g),
+                       0.1 * torch.randn(nw, generator=g)])
+    ref = cpu_ref.bigvgan_mel_spectrogram(wav)
+    out = MelSpec(mel_spec_type="bigvgan")(wav.cuda()).cpu()
+    assert out.shape == ref.shape == (2, 100, (nw + 768 - 1024) // 256 + 1)
+    strong = ref > math.log(1e-4)
+    assert (out - ref)[strong].abs().max() < 2e-3 and (out - ref).abs().max() < 5e-2

@@ -285,3 +285,28 @@ def test_rope_layout_switch_of_the_oracle():
     b = cpu_ref.apply_rope(t[..., perm], ang, half_split=False)
     assert torch.equal(a, b)
     assert not torch.allclose(cpu_ref.apply_rope(t, ang, True), cpu_ref.apply_rope(t, ang, False))
+
+
+def test_bigvgan_mel_front_end_matches_reference():
+    """the other vocoder's mel front-end.  tests/golden/bigvgan_mel.npz holds what the reference's own get_bigvgan_mel_spectrogram
+    (modules.py:29-72) returned for seeded waveforms; the oracle restates that function.  The one third-party piece, librosa's filterbank (absent
+    from the reference tree), is restated from the published algorithm and checked through its defining properties: Slaney normalisation = unit
+    area in Hz for every filter that lies inside the spectrum, one peak per filter, band edges equally spaced on the Slaney mel scale."""
+    import numpy as np
+    z = load_golden("bigvgan_mel")
+    wave = torch.from_numpy(z["wave"])
+    mel = cpu_ref.bigvgan_mel_spectrogram(wave)
+    assert mel.shape == z["mel"].shape == (2, 100, 93) and (mel - torch.from_numpy(z["mel"])).abs().max() < 1e-5
+    odd = cpu_ref.bigvgan_mel_spectrogram(wave[:1, :7777])
+    assert odd.shape == z["mel_7777"].shape == (1, 100, 30) and (odd - torch.from_numpy(z["mel_7777"])).abs().max() < 1e-5
+    fb = cpu_ref.librosa_mel_filterbank(24000, 1024, 100)
+    assert fb.shape == (100, 513) and np.allclose(fb.sum(axis=1), z["fb_rowsum"]) and (fb >= 0).all()
+    df = 24000 / 1024
+    area = fb.astype(np.float64).sum(axis=1) * df  # integral over Hz of a filter sampled at the FFT bins
+    # (the filters below ~1.5 kHz are about two bins wide: up to 12 % sampling error of the integral, not of the normalisation; the wide ones are exact)
+    assert np.abs(area - 1.0).max() < 0.15 and np.abs(area[60:] - 1.0).max() < 5e-3
+    peaks = fb.argmax(axis=1)
+    assert (np.diff(peaks) > 0).all() and peaks[0] >= 1 and peaks[-1] <= 511
+    # below 1 kHz the scale is linear: equal spacing of the band centres in Hz
+    low = peaks[:20] * df
+    assert np.abs(np.diff(low) - np.diff(low).mean()).max() <= df + 1e-9
