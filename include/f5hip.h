@@ -108,6 +108,8 @@ F5_API int f5_model_set_tensor(f5_model_t m, const char* name, const float* host
 F5_API int f5_model_has_tensor(f5_model_t m, const char* name, int64_t* numel);
 /* builds the fused device layouts (QKV concat, split input projection, rearranged grouped-conv taps, bf16 copies) */
 F5_API int f5_model_finalize(f5_model_t m);
+/* Destroy every plan of a model BEFORE the model: a plan may hold one of the model's LayerNorm-fold tables (round 4: per-time-grid weights
+ * W' = fp16(W (1 + scale)), up to two grids per model, 231 MB per evaluation time at F5TTS_Base; built by the first f5_sample on a grid). */
 F5_API int f5_model_destroy(f5_model_t m);
 
 /* ------------------------------------------------------------------ plan (workspace for one (batch, seq) bucket) */

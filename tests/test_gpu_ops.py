@@ -456,6 +456,7 @@ def test_attention_tuned_kernel_spiked_scores():
     (1024, 1024, 2048, 2048, 0),  # F5TTS_Base FF1 behind an FF2-shaped producer
     (1100, 1024, 2048, 1024, 0),  # M % 256 != 0: whole tiles on the persistent schedule + a tail launch
     (512, 1024, 3072, 1024, 4),   # fewer tiles than CUs
+    (4096, 1024, 3072, 1024, -16),  # persistent 256 x 256 tiles with RoPE on ALL 16 heads (F5TTS_v1_Base: pe_attn_head = null)
 ])
 @pytest.mark.parametrize("offset", [0.0, 40.0])
 def test_layernorm_fold_site_against_fp64(M, D, N, Kb, epi, offset):
@@ -464,6 +465,9 @@ def test_layernorm_fold_site_against_fp64(M, D, N, Kb, epi, offset):
     common offset of 40 standard deviations on every row, where a plain sum-of-squares form would lose its digits: the pivot is the row's
     previous mean --, (3) Linear(LN(x) (1 + scale) + shift) comes out of the fp16 GEMM + fold epilogue with bf16 output rounding only."""
     import gpu_helpers as G
+    rope_heads = 1
+    if epi < 0:
+        rope_heads, epi = -epi, 4
     g = torch.Generator().manual_seed(M + N + int(offset))
     x = torch.randn(M, D, generator=g) * 1.7 + offset + torch.randn(M, 1, generator=g) * 0.5
     A = G.bf16_round(torch.randn(M, Kb, generator=g))
@@ -481,7 +485,7 @@ def test_layernorm_fold_site_against_fp64(M, D, N, Kb, epi, offset):
     xh = x.half().float()
     pivot = torch.stack([xh.mean(dim=1) + 0.01, torch.ones(M)], dim=1) if offset else None  # "previous mean": near, not equal to, the new one
     xs, stats, out = G.op_ln_fold(epi, x, A, Wo, bo, gate, W, bias, scale, shift, pivot=pivot, act="gelu_tanh" if epi == 0 else "none", rope=rope,
-                                  rope_heads=1, seq=seq)
+                                  rope_heads=rope_heads, seq=seq)
     # (1) the stream: x + gate * (A Wo^T + bo), stored as fp16
     want = xh.double() + gate.double() * (A.double() @ Wo.double().t() + bo.double())
     assert (xs.double() - want).abs().max() <= want.abs().max() * 2.0 ** -10  # within one fp16 ulp of the exact sum
@@ -501,9 +505,11 @@ def test_layernorm_fold_site_against_fp64(M, D, N, Kb, epi, offset):
         pos = torch.arange(M) % seq
         cs = rope.double()[pos].reshape(M, 32, 2)
         for part in (0, 1):
-            blk = ref[:, part * inner: part * inner + 64].reshape(M, 32, 2)
-            rot = torch.stack([blk[..., 0] * cs[..., 0] - blk[..., 1] * cs[..., 1], blk[..., 1] * cs[..., 0] + blk[..., 0] * cs[..., 1]], dim=-1)
-            r[:, part * inner: part * inner + 64] = rot.reshape(M, 64)
+            for hd in range(rope_heads):
+                c0 = part * inner + hd * 64
+                blk = ref[:, c0: c0 + 64].reshape(M, 32, 2)
+                rot = torch.stack([blk[..., 0] * cs[..., 0] - blk[..., 1] * cs[..., 1], blk[..., 1] * cs[..., 0] + blk[..., 0] * cs[..., 1]], dim=-1)
+                r[:, c0: c0 + 64] = rot.reshape(M, 64)
         ref = r
     err = rel_l2(out, ref)
     print(f"ln_fold M={M} D={D} N={N} epi={epi} offset={offset}: rel-L2 {err:.2e}")
