@@ -33,6 +33,13 @@ class VocosConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_mels", "dim", "inter_dim", "layers", "n_fft", "hop")]
 
 
+class BigVGANConfig(C.Structure):  # struct f5_bigvgan_config
+    _fields_ = [("num_mels", C.c_int32), ("upsample_initial_channel", C.c_int32), ("num_upsamples", C.c_int32), ("upsample_rates", C.c_int32 * 8),
+                ("upsample_kernel_sizes", C.c_int32 * 8), ("num_kernels", C.c_int32), ("resblock_kernel_sizes", C.c_int32 * 4),
+                ("resblock_dilations", (C.c_int32 * 3) * 4), ("snake_logscale", C.c_int32), ("use_tanh_at_final", C.c_int32),
+                ("use_bias_at_final", C.c_int32)]
+
+
 class MelConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_fft", "hop", "win", "n_mels", "sample_rate", "mel_type")]
 
@@ -89,6 +96,12 @@ _PROTOS = {
     "f5_vocoder_destroy": (_I, [_P]),
     "f5_vocoder_decode": (_I, [_P, _I, _I, _P, _P, _P]),
     "f5_vocoder_istft_head": (_I, [_P, _I, _I, _P, _P, _P]),
+    "f5_bigvgan_create": (_I, [C.POINTER(BigVGANConfig), C.POINTER(_P)]),
+    "f5_bigvgan_set_tensor": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I]),
+    "f5_bigvgan_has_tensor": (_I, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
+    "f5_bigvgan_finalize": (_I, [_P]),
+    "f5_bigvgan_destroy": (_I, [_P]),
+    "f5_bigvgan_forward": (_I, [_P, _I, _I, _P, _P, _P]),
     "f5_frontend_create": (_I, [C.POINTER(MelConfig), C.POINTER(_P)]),
     "f5_frontend_destroy": (_I, [_P]),
     "f5_frontend_mel": (_I, [_P, _I, _I, _P, _P, _P]),

@@ -169,7 +169,7 @@ def infer_prompts(cfm, prompts_all: Sequence, vocoder=None, mode="ragged", nfe_s
             gen_mel_spec = gen.permute(0, 2, 1).to(torch.float32)
             wave = None
             if vocoder is not None:
-                wave = vocoder.decode(gen_mel_spec)
+                wave = vocoder.decode(gen_mel_spec) if hasattr(vocoder, "decode") else vocoder(gen_mel_spec).squeeze(0)  # eval_infer_batch.py:186-189
                 if ref_rms_list[i] < target_rms:
                     wave = wave * ref_rms_list[i] / target_rms
             yield utts[i], gen_mel_spec, wave

@@ -263,7 +263,10 @@ class F5TTSWrapper:
                 if n_streams > 1:
                     generated.record_stream(main)
                 generated = generated.to(torch.float32)[:, self.ref_audio_len:, :].permute(0, 2, 1)
-                generated_wave = self.vocoder.decode(generated)
+                if self.mel_spec_type == "vocos":
+                    generated_wave = self.vocoder.decode(generated)
+                elif self.mel_spec_type == "bigvgan":
+                    generated_wave = self.vocoder(generated)
                 rms = torch.sqrt(torch.mean(torch.square(self.ref_audio_processed)))  # of the stored, already boosted prompt (:529-531)
                 if rms < self.target_rms:
                     generated_wave = generated_wave * rms / self.target_rms

@@ -60,10 +60,18 @@ def chunk_text(text, max_chars=135):
 
 
 def load_vocoder(vocoder_name="vocos", is_local=False, local_path="", device=device, hf_cache_dir=None):
-    """Plug point B.  Only local Vocos weights can be loaded (there is no network): ``{local_path}/config.yaml`` +
+    """Plug point B.  Only local weights can be loaded (there is no network): BigVGAN from ``{local_path}/config.json`` + ``bigvgan_generator.pt``; Vocos from ``{local_path}/config.yaml`` +
     ``{local_path}/pytorch_model.bin`` as the reference's is_local branch reads them (:104-107,113-124)."""
+    if vocoder_name == "bigvgan":  # reference :125-138 (parity unpinned: the BigVGAN checkout is absent from the reference tree, see eraxvif5tts_amd/bigvgan.py)
+        from ..bigvgan import BigVGAN
+        if not is_local:
+            raise RuntimeError("snapshot_download of nvidia/bigvgan_v2_24khz_100band_256x is not possible offline: pass is_local=True with a local directory "
+                               "(config.json + bigvgan_generator.pt)")
+        vocoder = BigVGAN.from_pretrained(local_path, use_cuda_kernel=False)
+        vocoder.remove_weight_norm()
+        return vocoder.eval().to(device)
     if vocoder_name != "vocos":
-        raise NotImplementedError("only the Vocos vocoder is implemented on the MI355X path (BigVGAN is out of scope)")
+        raise NotImplementedError(f"vocoder {vocoder_name}: vocos and bigvgan are the reference's two")
     from ..vocos import Vocos
     if not is_local:
         raise RuntimeError("Download Vocos from huggingface charactr/vocos-mel-24khz is not possible offline: pass "
@@ -215,7 +223,7 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
 
     def finish_batch(generated):  # mel -> wave (reference :481-497)
         generated = generated.to(torch.float32)[:, ref_audio_len:, :].permute(0, 2, 1)
-        generated_wave = vocoder.decode(generated)
+        generated_wave = vocoder.decode(generated) if mel_spec_type == "vocos" else vocoder(generated)  # reference :485-488
         if rms < target_rms:
             generated_wave = generated_wave * rms / target_rms
         return generated_wave.squeeze().cpu().numpy(), generated[0].cpu().numpy()

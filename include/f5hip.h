@@ -297,6 +297,34 @@ F5_API int f5_vocoder_decode(f5_vocoder_t v, int B, int T, const float* mel, flo
  * log-magnitude | phase) -> wave dev f32 [B, (T-1)*hop] */
 F5_API int f5_vocoder_istft_head(f5_vocoder_t v, int B, int T, const float* head_out, float* wave, f5_stream_t stream);
 
+/* ------------------------------------------------------------------ BigVGAN-v2 generator (round 4; plug point B, PARITY UNPINNED)
+ * Replaces `third_party.BigVGAN.bigvgan.BigVGAN` as the reference uses it: infer/utils_infer.py:125-138 (from_pretrained + remove_weight_norm) and the
+ * call `vocoder(mel)` of infer/f5tts_wrapper.py:526 / eval/eval_infer_batch.py:189.  That checkout is absent from the reference tree: the generator is
+ * restated from the published BigVGAN-v2 source (conv_pre, per stage ConvTranspose1d + the mean of three AMPBlock1 with anti-aliased SnakeBeta
+ * activations, conv_post, clamp / tanh); tensor names are the checkpoint's with weight norm REMOVED (`<module>.weight`, `.bias`, `....act.alpha`,
+ * `....act.beta`), plus the optional 12-tap buffers `aa_up_filter` / `aa_down_filter` (default: the Kaiser-windowed sinc of the published filter). */
+typedef struct f5_bigvgan_s* f5_bigvgan_t;
+typedef struct f5_bigvgan_config {
+    int32_t num_mels;                 /* 100 */
+    int32_t upsample_initial_channel; /* 1536 */
+    int32_t num_upsamples;            /* 6 (<= 8) */
+    int32_t upsample_rates[8];        /* 4 4 2 2 2 2 */
+    int32_t upsample_kernel_sizes[8]; /* 8 8 4 4 4 4 (a multiple of the rate, k - u even) */
+    int32_t num_kernels;              /* 3 (<= 4) AMP blocks per stage */
+    int32_t resblock_kernel_sizes[4]; /* 3 7 11 */
+    int32_t resblock_dilations[4][3]; /* 1 3 5 each */
+    int32_t snake_logscale;           /* 1: alpha / beta are stored as logarithms */
+    int32_t use_tanh_at_final;        /* 0: clamp(-1, 1) */
+    int32_t use_bias_at_final;        /* 0: conv_post has no bias */
+} f5_bigvgan_config;
+F5_API int f5_bigvgan_create(const f5_bigvgan_config* cfg, f5_bigvgan_t* out);
+F5_API int f5_bigvgan_set_tensor(f5_bigvgan_t v, const char* name, const float* host_data, const int64_t* shape, int ndim);
+F5_API int f5_bigvgan_has_tensor(f5_bigvgan_t v, const char* name, int64_t* numel);
+F5_API int f5_bigvgan_finalize(f5_bigvgan_t v);
+F5_API int f5_bigvgan_destroy(f5_bigvgan_t v);
+/* mel dev f32 [B][num_mels][T] -> wave dev f32 [B][T * prod(upsample_rates)]  (BigVGAN.forward, the [B, 1, samples] result without its unit axis) */
+F5_API int f5_bigvgan_forward(f5_bigvgan_t v, int B, int T, const float* mel, float* wave, f5_stream_t stream);
+
 /* ------------------------------------------------------------------ reference-audio front-end on the device
  * Replaces the two torchaudio transforms of the path:
  *   f5_frontend_mel       MelSpec / get_vocos_mel_spectrogram, reference model/modules.py:75-143 (as called from cfm.py:103-105):

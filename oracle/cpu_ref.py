@@ -746,6 +746,114 @@ def generate_chain(W, cfg, V, ref_audio, ref_text_nbytes, chunks, *, nfe_step=32
     return cross_fade_concat(waves, cross_fade_duration, sr), mels
 
 
+# ----------------------------------------------------------------------------- f4: the BigVGAN vocoder (parity UNPINNED)
+# The reference loads it from a third-party checkout (infer/utils_infer.py:125-138: `from third_party.BigVGAN import bigvgan`,
+# BigVGAN.from_pretrained("nvidia/bigvgan_v2_24khz_100band_256x"), remove_weight_norm()) that is ABSENT from /root/reference, and calls
+# `vocoder(mel)` (f5tts_wrapper.py:526, eval_infer_batch.py:189).  What follows restates the PUBLISHED BigVGAN-v2 generator (NVIDIA/BigVGAN
+# bigvgan.py, activations.py, alias_free_activation/torch/{act,resample,filter}.py) as recalled: conv_pre k7 -> per stage ConvTranspose1d(k, u,
+# padding (k - u) / 2) then the mean of three AMPBlock1 (kernel 3 / 7 / 11, dilations 1, 3, 5; anti-aliased SnakeBeta in front of every conv) ->
+# anti-aliased SnakeBeta -> conv_post k7 -> clamp(-1, 1) (tanh when use_tanh_at_final).  Nothing pins it: no source, no checkpoint, no reference test.
+BIGVGAN_V2_24K_100BAND_256X = dict(num_mels=100, upsample_initial_channel=1536, upsample_rates=[4, 4, 2, 2, 2, 2], upsample_kernel_sizes=[8, 8, 4, 4, 4, 4],
+                                   resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], snake_logscale=True,
+                                   use_tanh_at_final=False, use_bias_at_final=False)
+
+
+def kaiser_sinc_filter1d(cutoff, half_width, kernel_size):
+    """alias_free_activation/torch/filter.py: Kaiser-windowed sinc low-pass, normalised to unit sum -> [kernel_size]."""
+    even = kernel_size % 2 == 0
+    half_size = kernel_size // 2
+    delta_f = 4 * half_width
+    A = 2.285 * (half_size - 1) * math.pi * delta_f + 7.95
+    beta = 0.1102 * (A - 8.7) if A > 50.0 else (0.5842 * (A - 21) ** 0.4 + 0.07886 * (A - 21.0) if A >= 21.0 else 0.0)
+    window = torch.kaiser_window(kernel_size, beta=beta, periodic=False)
+    time = (torch.arange(-half_size, half_size) + 0.5) if even else (torch.arange(kernel_size) - half_size)
+    filt = 2 * cutoff * window * torch.sinc(2 * cutoff * time)
+    return filt / filt.sum()
+
+
+def _aa_snake(x, alpha, beta, up_f, dn_f, logscale):
+    """Activation1d(SnakeBeta): UpSample1d(2, 12) -> x + sin^2(alpha x) / (beta + 1e-9) -> DownSample1d(2, 12).  x [b, C, T]."""
+    C = x.shape[1]
+    ratio, k = 2, up_f.numel()
+    pad = k // ratio - 1
+    pad_left, pad_right = pad * ratio + (k - ratio) // 2, pad * ratio + (k - ratio + 1) // 2
+    u = F.pad(x, (pad, pad), mode="replicate")
+    u = ratio * F.conv_transpose1d(u, up_f.view(1, 1, -1).expand(C, -1, -1), stride=ratio, groups=C)[..., pad_left:-pad_right]
+    a, b = alpha.view(1, -1, 1), beta.view(1, -1, 1)
+    if logscale:
+        a, b = torch.exp(a), torch.exp(b)
+    u = u + (1.0 / (b + 1e-9)) * torch.sin(u * a) ** 2
+    kd = dn_f.numel()
+    u = F.pad(u, (kd // 2 - int(kd % 2 == 0), kd // 2), mode="replicate")
+    return F.conv1d(u, dn_f.view(1, 1, -1).expand(C, -1, -1), stride=ratio, groups=C)
+
+
+def bigvgan_forward(W, hp, mel):
+    """mel [b, num_mels, T] -> wave [b, 1, T * prod(upsample_rates)].  W: state dict with weight norm REMOVED (`...weight`, `...bias`)."""
+    up_f = W.get("aa_up_filter", kaiser_sinc_filter1d(0.25, 0.3, 12))
+    dn_f = W.get("aa_down_filter", kaiser_sinc_filter1d(0.25, 0.3, 12))
+    ls = bool(hp.get("snake_logscale", True))
+    nk = len(hp["resblock_kernel_sizes"])
+    x = F.conv1d(mel.float(), W["conv_pre.weight"], W["conv_pre.bias"], padding=3)
+    for i, (u, k) in enumerate(zip(hp["upsample_rates"], hp["upsample_kernel_sizes"])):
+        x = F.conv_transpose1d(x, W[f"ups.{i}.0.weight"], W[f"ups.{i}.0.bias"], stride=u, padding=(k - u) // 2)
+        xs = None
+        for j, (ks, dil) in enumerate(zip(hp["resblock_kernel_sizes"], hp["resblock_dilation_sizes"])):
+            p = f"resblocks.{i * nk + j}."
+            y = x
+            for t, d in enumerate(dil):
+                xt = _aa_snake(y, W[p + f"activations.{2 * t}.act.alpha"], W[p + f"activations.{2 * t}.act.beta"], up_f, dn_f, ls)
+                xt = F.conv1d(xt, W[p + f"convs1.{t}.weight"], W[p + f"convs1.{t}.bias"], dilation=d, padding=(ks * d - d) // 2)
+                xt = _aa_snake(xt, W[p + f"activations.{2 * t + 1}.act.alpha"], W[p + f"activations.{2 * t + 1}.act.beta"], up_f, dn_f, ls)
+                xt = F.conv1d(xt, W[p + f"convs2.{t}.weight"], W[p + f"convs2.{t}.bias"], padding=(ks - 1) // 2)
+                y = xt + y
+            xs = y if xs is None else xs + y
+        x = xs / nk
+    x = _aa_snake(x, W["activation_post.act.alpha"], W["activation_post.act.beta"], up_f, dn_f, ls)
+    x = F.conv1d(x, W["conv_post.weight"], W.get("conv_post.bias"), padding=3)
+    return torch.tanh(x) if hp.get("use_tanh_at_final", True) else torch.clamp(x, -1.0, 1.0)
+
+
+def bigvgan_param_shapes(hp):
+    C0 = hp["upsample_initial_channel"]
+    shapes = {"conv_pre.weight": (C0, hp["num_mels"], 7), "conv_pre.bias": (C0,)}
+    nk = len(hp["resblock_kernel_sizes"])
+    ch = C0
+    for i, (u, k) in enumerate(zip(hp["upsample_rates"], hp["upsample_kernel_sizes"])):
+        shapes[f"ups.{i}.0.weight"] = (ch, ch // 2, k)
+        shapes[f"ups.{i}.0.bias"] = (ch // 2,)
+        ch //= 2
+        for j, (ks, dil) in enumerate(zip(hp["resblock_kernel_sizes"], hp["resblock_dilation_sizes"])):
+            p = f"resblocks.{i * nk + j}."
+            for t in range(len(dil)):
+                for cv in ("convs1", "convs2"):
+                    shapes[p + f"{cv}.{t}.weight"] = (ch, ch, ks)
+                    shapes[p + f"{cv}.{t}.bias"] = (ch,)
+            for a in range(2 * len(dil)):
+                shapes[p + f"activations.{a}.act.alpha"] = (ch,)
+                shapes[p + f"activations.{a}.act.beta"] = (ch,)
+    shapes["activation_post.act.alpha"] = (ch,)
+    shapes["activation_post.act.beta"] = (ch,)
+    shapes["conv_post.weight"] = (1, ch, 7)
+    if hp.get("use_bias_at_final", True):
+        shapes["conv_post.bias"] = (1,)
+    return shapes
+
+
+def random_bigvgan_weights(hp, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    W = {}
+    for name, shape in bigvgan_param_shapes(hp).items():
+        if name.endswith(".alpha") or name.endswith(".beta"):
+            W[name] = torch.randn(shape, generator=g) * 0.3  # (log scale: exp(.) around 1)
+        elif name.endswith(".bias"):
+            W[name] = torch.randn(shape, generator=g) * 0.05
+        else:
+            fan_in = shape[1] * shape[2] if not name.startswith("ups.") else shape[0] * shape[2] / 2
+            W[name] = torch.randn(shape, generator=g) * (1.0 / math.sqrt(max(fan_in, 1.0)))
+    return W
+
+
 # ----------------------------------------------------------------------------- duration predictor (SURVEY 8f-2)
 def duration_predictor(W, tokens, mask, add_one=True, prefix="", g_cond=None):
     """DurationPredictor.forward (model/duration_predictor.py:28-46; phoneme_forward :48-68 with add_one=False):

@@ -410,3 +410,70 @@ def test_generate_long_form_chunks_and_cross_fade(tmp_path):
     torch.manual_seed(21)
     serial, _ = tts.generate(text, nfe_step=2, return_numpy=True)
     assert np.array_equal(serial, faded)
+
+
+BIGVGAN_TINY = dict(num_mels=100, upsample_initial_channel=192, upsample_rates=[4, 4, 2, 2, 2, 2], upsample_kernel_sizes=[8, 8, 4, 4, 4, 4],
+                    resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], snake_logscale=True,
+                    use_tanh_at_final=False, use_bias_at_final=False)
+
+
+@pytest.mark.parametrize("T,variant", [(13, "v2"), (40, "v2"), (77, "tanh_bias"), (5, "v2")])
+def test_bigvgan_forward_matches_oracle(T, variant):
+    """SURVEY 8(f).4, PARITY UNPINNED (the BigVGAN checkout is absent from the reference tree): csrc/bigvgan.hip against the oracle's restatement of the
+    published BigVGAN-v2 generator (oracle/cpu_ref.bigvgan_forward: torch conv1d / conv_transpose1d, anti-aliased SnakeBeta with the Kaiser-sinc
+    filters) on a narrow network of the v2 topology (6 stages x 3 AMP blocks, x256), random weights scaled so that the final clamp is not saturated;
+    fp32-input MFMA: rel-L2 <= 1e-4.  Variant tanh_bias: use_tanh_at_final / use_bias_at_final (the v1 form)."""
+    from eraxvif5tts_amd.bigvgan import BigVGAN
+    hp = dict(BIGVGAN_TINY)
+    if variant == "tanh_bias":
+        hp.update(use_tanh_at_final=True, use_bias_at_final=True, snake_logscale=False)
+    W = cpu_ref.random_bigvgan_weights(hp, seed=T)
+    if not hp["snake_logscale"]:
+        for k in W:
+            if k.endswith(".alpha") or k.endswith(".beta"):
+                W[k] = W[k].abs() + 0.5
+    W["conv_post.weight"] = W["conv_post.weight"] * 0.0015
+    mel = torch.randn(2, 100, T, generator=torch.Generator().manual_seed(T + 1)) * 2 - 3
+    ref = cpu_ref.bigvgan_forward(W, hp, mel)
+    assert ref.shape == (2, 1, T * 256) and float((ref.abs() >= 0.999).float().mean()) < 0.01  # (almost) never saturated: the comparison sees the whole network
+    voc = BigVGAN(hp)
+    voc.load_state_dict(W)
+    voc = voc.eval().cuda()
+    out = voc(mel.cuda()).cpu()
+    assert out.shape == ref.shape and rel_l2(out, ref) < 1e-4
+    assert voc.remove_weight_norm() is voc
+
+
+def test_bigvgan_checkpoint_directory_and_weight_norm(tmp_path):
+    """from_pretrained on a local directory in the layout of nvidia/bigvgan_v2_24khz_100band_256x (config.json + bigvgan_generator.pt with
+    {"generator": ...}), weight-normed convolutions (weight_g / weight_v) and the Activation1d filter buffers folded at load time, through
+    utils_infer.load_vocoder("bigvgan", is_local=True) as the reference's branch does (utils_infer.py:125-138)."""
+    import json
+
+    from eraxvif5tts_amd.infer import utils_infer as U
+    hp = dict(BIGVGAN_TINY, resblock="1", activation="snakebeta")
+    W = cpu_ref.random_bigvgan_weights(hp, seed=9)
+    W["conv_post.weight"] = W["conv_post.weight"] * 0.0015
+    ck = {}
+    g = torch.Generator().manual_seed(10)
+    for k, v in W.items():
+        if k.endswith(".weight"):  # weight = g * v / ||v||: store a rescaled direction and the matching magnitude
+            vv = v * (0.5 + torch.rand(v.shape[0], generator=g)).reshape(-1, *([1] * (v.ndim - 1)))
+            ck[k[:-len("weight")] + "weight_v"] = vv
+            ck[k[:-len("weight")] + "weight_g"] = v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, *([1] * (v.ndim - 1)))
+        else:
+            ck[k] = v
+    filt = cpu_ref.kaiser_sinc_filter1d(0.25, 0.3, 12).reshape(1, 1, 12)
+    ck["activation_post.upsample.filter"] = filt
+    ck["activation_post.downsample.lowpass.filter"] = filt
+    ck["resblocks.0.activations.0.upsample.filter"] = filt
+    ck["resblocks.0.activations.0.downsample.lowpass.filter"] = filt
+    d = str(tmp_path)
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump(hp, f)
+    torch.save({"generator": ck}, os.path.join(d, "bigvgan_generator.pt"))
+    voc = U.load_vocoder("bigvgan", is_local=True, local_path=d, device="cuda")
+    mel = torch.randn(1, 100, 21, generator=g) * 2 - 3
+    assert rel_l2(voc(mel.cuda()).cpu(), cpu_ref.bigvgan_forward(W, hp, mel)) < 1e-4
+    with pytest.raises(RuntimeError):
+        U.load_vocoder("bigvgan", is_local=False)
