@@ -412,6 +412,31 @@ def extra_workloads(args, dev, model, cfm):
     # form (the reference's) against the ragged sampler (no padding, no key mask, a prompt per utterance); third pass of each (the second
     # pass of a shape captures its hipGraph, the third replays it).
     out.update(bucketed_workloads(args, dev, cfm, nfe))
+    try:  # the other vocoder of plug point B (parity unpinned, not tuned: DESIGN section 9): one 683-frame utterance through the BigVGAN-v2 generator
+        from eraxvif5tts_amd.bigvgan import BigVGAN
+        from oracle import cpu_ref as _cr  # (only its seeded weight generator: random init of the published shapes, no checkpoint offline)
+        bw = _cr.random_bigvgan_weights(_cr.BIGVGAN_V2_24K_100BAND_256X, seed=1)
+        bw["conv_post.weight"] = bw["conv_post.weight"] * 0.0015
+        voc = BigVGAN()
+        voc.load_state_dict(bw)
+        voc = voc.eval().to(dev)
+        bmel = (torch.randn(1, 100, 683, generator=torch.Generator().manual_seed(2)) * 2 - 3).clamp(math.log(1e-5), 3.0).to(dev)
+        w = voc(bmel)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            w = voc(bmel)
+        torch.cuda.synchronize()
+        bms = (time.perf_counter() - t0) / 5 * 1e3
+        assert torch.isfinite(w).all()
+        out["bigvgan_decode"] = {"value": round(683 / bms * 1e3, 2), "unit": "mel-frames/s", "ms_per_step": round(bms, 3),
+                                 "rtf": round(bms / 1e3 / (683 * 256 / 24000.0), 6),
+                                 "config": "BigVGAN-v2 generator (bigvgan_v2_24khz_100band_256x shape, 112.4 M parameters, random init), mel [1, 100, 683] -> "
+                                           "wave [1, 1, 174848], fp32-input MFMA; parity unpinned (source absent from the reference tree)"}
+        del voc, bw, w, bmel
+        torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001
+        out["bigvgan_decode_error"] = f"{type(e).__name__}: {e}"
     v = bench_vocos(args, dev, T=683, B=32, steps=20, warmup=3)
     out["C5"] = {"value": v["value"], "unit": v["unit"], "ms_per_step": v["ms_per_step"], "rtf": v["rtf"], "config": v["config"]["workload"],
                  "head_gbs": v["roofline"]["achieved"], "head_frac": v["roofline"]["frac"],
