@@ -181,6 +181,41 @@ def test_in_kernel_row_statistics_equal_the_statistics_kernel():
     assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
 
 
+def test_fold_tables_follow_the_time_grid_across_graphs_and_streams():
+    """The LayerNorm-fold tables are per TIME GRID, owned by the model (at most two), shared by its plans, and captured graphs bake their addresses:
+    alternate three grids (NFE 3 / 4 / 5: the third evicts the first) with hipGraph replay on two streams, F5TTS_Base width at depth 4 -- every
+    result must equal the eager result of the same grid computed on a model of its own, bit for bit."""
+    import bench
+    from eraxvif5tts_amd.model import CFM, DiT
+    arch = dict(bench.BASE_ARCH, depth=4)
+
+    def make():
+        torch.manual_seed(777)
+        m = bench.synth_weights(DiT(**arch, text_num_embeds=bench.VOCAB, mel_dim=100, precision="bf16"), seed=0)
+        return CFM(transformer=m, mel_spec_kwargs={"mel_spec_type": "vocos"}).cuda()
+    cond, text, lens, dur = bench.synth_batch(2, 640, "cuda", seed=31)
+    y0 = torch.randn(2, 640, 100, generator=torch.Generator().manual_seed(32))
+    kw = dict(cond=cond, text=text, duration=dur, lens=lens, cfg_strength=2.0, sway_sampling_coef=-1.0, y0=y0, return_trajectory=False)
+    want = {}
+    for nfe in (3, 4, 5):
+        ref = make()
+        want[nfe] = ref.sample(steps=nfe, use_graph=False, **kw)[0].cpu()
+        del ref
+        torch.cuda.empty_cache()
+    cfm = make()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    for rnd in range(3):  # round 0 eager + capture, later rounds replay; the grids alternate, so tables and graphs are switched every call
+        for nfe in (3, 4, 5, 4, 3):
+            out = cfm.sample(steps=nfe, use_graph=True, **kw)[0]
+            assert torch.equal(out.cpu(), want[nfe]), (rnd, nfe)
+            with torch.cuda.stream(side):  # another stream = another plan of the same model: it finds the grid's table (or rebuilds an evicted one)
+                out2 = cfm.sample(steps=nfe, use_graph=rnd > 0, **kw)[0]
+            side.synchronize()
+            assert torch.equal(out2.cpu(), want[nfe]), (rnd, nfe, "side stream")
+    assert cfm.transformer.residual_fallbacks() == 0
+
+
 def test_bench_path_equal_durations_full_batch_against_fp32_mode():
     """The exact path `bench.py` times at C2: 32 utterances x 1024 frames, ALL durations equal, so CFM.sample asks for the unmasked kernels
     (attn_wide_kernel<false>, mask-free GEMM epilogues, persistent 256 x 256 tiles at 65 536 token rows), bf16, hipGraph replay.  Utterances
