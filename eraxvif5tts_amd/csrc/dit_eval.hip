@@ -84,10 +84,27 @@ int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, const float
         t.N = ff;
         ink_ff1 = gemm_fast_lnf_inkernel(t);
     }
-    // consumer side of site k: finalized statistics (one more launch, which also prefetches `pf`) or the in-kernel form
+    // producer side of site k (out-projection, FF2): the non-persistent schedules (small batches) finish the statistics inside the launch -- the
+    // workgroup that completes a block of token rows last turns the partial sums into (mean, rstd), carries the range guard and leaves nothing
+    // for a statistics launch to do (gemm.h: fin_counter; same bits as stats_finalize_kernel)
+    bool fin_site[2] = {false, false};  // [k & 1]: site k's statistics were finished by its producer
+    auto lnf_producer = [&](GemmParams& g, int k, int tag, const PrefetchSet& pf, bool consumer_inkernel) {
+        g.stats_out = p->lnf_partial; g.stats_ld = (int)p->rows_cap; g.stats_pivot = k > 0 ? lnfS[(k - 1) & 1] : nullptr;
+        const bool fin = g_ln_fold_fin && !consumer_inkernel && p->fin_counter && gemm_fast_resid_finishes(g);
+        fin_site[k & 1] = fin;
+        if (fin) {
+            g.fin_counter = p->fin_counter; g.fin_stats = lnfS[k & 1]; g.lnf_sat = sat; g.lnf_sat_tag = tag;
+        }
+        if (rows <= g_w_prefetch && r16 && g_w_prefetch && (fin || consumer_inkernel)) {  // no statistics launch behind this one: the GEMM itself touches the weights
+            g.pf_p[0] = pf.p[0]; g.pf_n[0] = pf.n[0]; g.pf_p[1] = pf.p[1]; g.pf_n[1] = pf.n[1];
+        }
+    };
+    // consumer side of site k: finalized statistics (by the producer, or one more launch, which also prefetches `pf`) or the in-kernel form
     auto lnf_consumer = [&](GemmParams& g, int k, bool inkernel, int site, int tag, const PrefetchSet* pf) -> int {
         const float* pivots = k > 0 ? lnfS[(k - 1) & 1] : nullptr;
-        if (!inkernel) {
+        if (!inkernel && fin_site[k & 1]) {
+            g.lnf_stats = lnfS[k & 1];
+        } else if (!inkernel) {
             F5_TRY(timed(p, site, st, [&] {
                 return launch_stats_finalize(p->lnf_partial, (int)p->rows_cap, D / 64, rows, D, pivots, lnfS[k & 1], sat, tag, st, pf);
             }));
@@ -223,12 +240,8 @@ int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, const float
             g.ldof = D;
             g.add2_f16 = 1;
         }
-        if (lnf) {  // partial row sums of the updated stream (site 2l); pivot = the row's previous mean (none yet at site 0: the tables are this evaluation's)
-            g.stats_out = p->lnf_partial; g.stats_ld = (int)p->rows_cap; g.stats_pivot = l > 0 ? lnfS[(2 * l - 1) & 1] : nullptr;
-            if (wpf && ink_ff1) {  // no statistics launch behind this one: the GEMM itself touches the weights of FF1 and FF2
-                g.pf_p[0] = pf2f.p[0]; g.pf_n[0] = pf2f.n[0]; g.pf_p[1] = pf2f.p[1]; g.pf_n[1] = pf2f.n[1];
-            }
-        }
+        // partial row sums of the updated stream (site 2l); pivot = the row's previous mean (none yet at site 0: the tables are this evaluation's)
+        if (lnf) lnf_producer(g, 2 * l, 2 | (l << 4), pf2f, ink_ff1);  // (prefetch: the weights of FF1 and FF2)
         F5_TRY(timed(p, F5_SITE_OUT, st, [&] { return run_gemm(p, g, GEMM_DENSE, rmw ? EPI_RESID : EPI_GATE_T, st); }));
         // x += y; n2 = LN(x) * (1 + scale_mlp) + shift_mlp
         if (!lnf) F5_TRY(timed(p, F5_SITE_LN2, st, [&] {
@@ -258,12 +271,7 @@ int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, const float
             g.add2_f16 = 1;
         }
         const bool lnf_next = lnf && l + 1 < c.depth;  // (the final AdaLN pass reads the stream itself)
-        if (lnf_next) {  // site 2l + 1
-            g.stats_out = p->lnf_partial; g.stats_ld = (int)p->rows_cap; g.stats_pivot = lnfS[(2 * l) & 1];
-            if (wpf && ink_qkv) {  // (see the out-projection) the next block's q|k|v weights and its out-projection
-                g.pf_p[0] = pf1f.p[0]; g.pf_n[0] = pf1f.n[0]; g.pf_p[1] = pf1f.p[1]; g.pf_n[1] = pf1f.n[1];
-            }
-        }
+        if (lnf_next) lnf_producer(g, 2 * l + 1, 1 | ((l + 1) << 4), pf1f, ink_qkv);  // site 2l + 1 (prefetch: the next block's q|k|v weights and its out-projection)
         F5_TRY(timed(p, F5_SITE_FF2, st, [&] { return run_gemm(p, g, GEMM_DENSE, rmw ? EPI_RESID : EPI_GATE_T, st); }));
         pf1f_prev = pf1f;  // (what a statistics launch in front of the next block's QKV projection prefetches)
     }

@@ -14,6 +14,11 @@ int g_ln_fold_inkernel = 0;  // tuning knob ("ln_fold_inkernel"): 1 = folded pro
                              // (tested), but measured slower where it applies -- 1 x 1024: 79.0 - 80.1 against 76.9 - 77.6 ms per sample(), 2 x 1024:
                              // 107.8 - 108.6 against 105.5 - 105.9 ms (gpurun_out/r4h_*): the 16 partial loads per row sit in front of a
                              // latency-bound main loop and cost more than the 44 small launches they replace.  Off.
+int g_ln_fold_fin = 0;  // tuning knob ("ln_fold_fin"): in-place residual GEMMs on the non-persistent schedules finish the row statistics inside the launch
+                        // (last workgroup of a token block; gemm.h: fin_counter) -- no statistics launch behind them.  Same bits as stats_finalize_kernel
+                        // (tested).  Measured (gpurun_out/r4p_ab.log, same box, alternating): the drain + ticket + last-arriver pass costs each residual
+                        // GEMM 3 - 4 us, the two statistics launches it replaces 6.5 us each: 1 x 1024 77.4 - 78.0 against 76.7 - 77.1 ms per sample(),
+                        // 2 x 1024 102.6 - 103.3 against 103.8, 4 x 1024 equal.  Off.
 int g_gemm_pad_rows = 1;  // tuning knob ("gemm_pad_rows"): the block GEMMs of a DiT evaluation run over the token rows rounded up to 256 (dit_eval)
 int g_sync_evals = 0;  // diagnostic knob ("sync_evals"): an eager sample() synchronises the stream after every network evaluation, which bounds the
                        // number of dispatches in flight (profiles/r3_rocprof_pmc_sigsegv.md: rocprofv3 --pmc died under ~5 400 queued dispatches)

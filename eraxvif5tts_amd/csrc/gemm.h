@@ -81,6 +81,13 @@ struct GemmParams {
     float* stats_out;
     int stats_ld;                // rows per 64-feature plane of stats_out
     const float* stats_pivot;    // [M][2]: element 0 of row m is the pivot (the row's previous mean), or null (pivot 0)
+    // ... and, on the non-persistent schedules, the statistics are FINISHED inside the same launch: the workgroup that completes a block of
+    // token rows last (fin_counter[m0 / BM], one ticket per feature tile) adds the row's partial sums in stats_finalize_kernel's order and stores
+    // (mean, rstd) to fin_stats [M][2] -- no statistics launch behind the GEMM.  Hand-off as /opt/skills/guides/cdna_hip_programming.md section 6,
+    // guideline 16 prescribes for a fan-in: write-through (agent-scope) partial stores, every wave drained, workgroup barrier, one relaxed agent-scope
+    // ticket; the last arriver acquires once and reads the partials with agent-scope loads; it also resets the ticket word.  Range guard: lnf_sat / lnf_sat_tag.
+    unsigned* fin_counter;
+    float* fin_stats;
     int tile_group;  // tuned kernel: token tiles per L2 patch (set by the launcher)
     int tile_reverse;  // tuned kernel: walk the tiles in the opposite order (producer / consumer cache experiments)
     int lean_epi;    // tuned kernel: whole tiles take the lean epilogue (set by the launcher; 0 = always the generic one)
@@ -95,6 +102,9 @@ bool gemm_fast_supported(const GemmParams& p, int precision, int mode, int epi);
 void gemm_fast_tile(const GemmParams& p, int* bm, int* bn);
 // LayerNorm fold: true when a launch of this shape can take its row statistics from the partial sums inside the kernel (every tile but 256 x 256)
 bool gemm_fast_lnf_inkernel(const GemmParams& p);
+// LayerNorm fold: true when an in-place residual launch with these parameters can finish its row statistics inside the launch
+// (GemmParams::fin_counter): every schedule but the PERSISTENT one, which leaves them to stats_finalize_kernel
+bool gemm_fast_resid_finishes(const GemmParams& p);
 // dedicated kernel for the dim-1024 grouped Conv1d(k = 31) of ConvPositionEmbedding (conv31.hip); GemmParams as for GEMM_CONV31
 bool conv31_supported(const GemmParams& p, int precision, int epi);
 int launch_conv31(const GemmParams& p, hipStream_t stream);

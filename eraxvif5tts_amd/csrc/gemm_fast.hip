@@ -378,7 +378,13 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
         float t = a0 + b0, z = 0.0f;
         asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(t), "+v"(z));
         const float tot = t + z;
-        if (fq < 2 && row_ok) p.stats_out[((size_t)((n0 + wn * WN) >> 6) * p.stats_ld + m) * 2 + fq] = tot;
+        if (fq < 2 && row_ok) {
+            float* dst = p.stats_out + ((size_t)((n0 + wn * WN) >> 6) * p.stats_ld + m) * 2 + fq;
+            if (p.fin_counter)  // read by another workgroup of THIS launch: agent-scope (write-through) store
+                __hip_atomic_store(dst, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                *dst = tot;
+        }
     };
     [[maybe_unused]] auto h_round4 = [](const f32x4& v) {  // what the fp16 stream holds after a saturating store of v
         f32x4 r;
@@ -933,6 +939,58 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p, int til
     }
 
     epilogue();
+    if constexpr (EPI == EPI_RESID && !PERSIST && !LNF) {
+        if (p.fin_counter) {
+            // LayerNorm fold: finish the row statistics of this block of token rows in the launch (gemm.h: fin_counter).  Every wave has stored
+            // its partial sums write-through; drain them, meet, draw ONE ticket per workgroup; the workgroup that draws the last one owns the block.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            unsigned* flag = reinterpret_cast<unsigned*>(smem);  // (the operand ring is dead: every wave is past its last fragment read)
+            if (tid == 0) *flag = __hip_atomic_fetch_add(p.fin_counter + m0 / BM, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (*flag == (unsigned)(tiles_n - 1)) {
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(p.fin_counter + m0 / BM, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+                }
+                __syncthreads();
+                bool bad = false;
+                float sumsq = 0.f;
+                const int m = m0 + tid;
+                if (tid < BM && m < p.M) {
+                    const int ncols = p.N >> 6;
+                    float s1 = 0.f, s2 = 0.f;
+                    if (ncols == 16) {
+                        float v1[16], v2[16];
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) {
+                            const float* src = p.stats_out + ((size_t)c * p.stats_ld + m) * 2;
+                            v1[c] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            v2[c] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) {
+                            s1 += v1[c];
+                            s2 += v2[c];
+                        }
+                    } else {
+                        for (int c = 0; c < ncols; ++c) {
+                            const float* src = p.stats_out + ((size_t)c * p.stats_ld + m) * 2;
+                            s1 += __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            s2 += __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                    const float pv = p.stats_pivot ? p.stats_pivot[(size_t)m * 2] : 0.0f;
+                    float mean, rstd;
+                    lnf_row_stats(s1, s2, pv, p.N, mean, rstd, sumsq);
+                    *reinterpret_cast<f32x2*>(p.fin_stats + (size_t)m * 2) = f32x2{mean, rstd};
+                    bad = !(sumsq < 65504.0f * 65504.0f);
+                }
+                lnf_raise_guard(p.lnf_sat, bad, sumsq, p.lnf_sat_tag, m + p.row0);
+            }
+        }
+    }
     clk_end();
 }
 
@@ -1106,6 +1164,15 @@ void gemm_fast_tile(const GemmParams& p, int* pbm, int* pbn) {
     *pbn = bn;
 }
 
+bool gemm_fast_resid_finishes(const GemmParams& p) {
+    int bm, bn;
+    gemm_fast_tile(p, &bm, &bn);
+    const bool resid_ok = p.add2_f16 && p.out_f && (p.ldof & 7) == 0 && p.act == ACT_NONE && (!p.gate || p.gate_bstride == 0) && (!p.rowmask || p.rowbits);
+    const bool persistent = bn == 256 && g_gemm_variant != 0 && g_gemm_persist && resid_ok && p.M % 256 == 0 && p.K >= 128 && p.N % 256 == 0 && p.bias;
+    const bool split = bn == 256 && g_gemm_split_tail && p.M % 256 != 0;  // (whole tiles on the persistent schedule + a tail launch)
+    return !persistent && !split && p.N % 64 == 0 && p.N / 64 <= 64;
+}
+
 bool gemm_fast_lnf_inkernel(const GemmParams& p) {
     int bm, bn;
     gemm_fast_tile(p, &bm, &bn);
@@ -1125,6 +1192,8 @@ int launch_gemm_fast(const GemmParams& p, int mode, int epi, hipStream_t stream)
         if (!p.lnf_c1 || !p.lnf_c2 || (epi != EPI_STORE_T && epi != EPI_ROPE_T)) return f5_fail(F5_EINVAL, "gemm_fast: LayerNorm fold needs c1, c2 and a store / RoPE epilogue");
         return launch_gemm_fast_lnf(p, epi, bm, bn, stream);
     }
+    if (p.fin_counter && (!p.stats_out || !p.fin_stats || epi != EPI_RESID || !gemm_fast_resid_finishes(p)))
+        return f5_fail(F5_ESTATE, "gemm_fast: statistics can be finished inside the launch by the non-persistent in-place residual schedules only");
     if (p.stats_out && (epi != EPI_RESID || !p.add2_f16 || p.N % 64 != 0 || p.stats_ld < p.M))
         return f5_fail(F5_EINVAL, "gemm_fast: row statistics need the in-place fp16 residual epilogue and N % 64 == 0");
 #define F5_FAST_CASE(E)                                                                   \

@@ -523,6 +523,7 @@ extern "C" int f5_plan_create(f5_model_t m, int max_batch, int max_seq, int max_
             if ((rc = A.alloc_t(&p->lnf_stats, (rows + 256) * 2))) break;
             if ((rc = A.alloc_t(&p->lnf_stats2, (rows + 256) * 2))) break;
             if ((rc = A.alloc_t(&p->lnf_partial, (D / 64) * rows * 2))) break;
+            if ((rc = A.alloc_t(&p->fin_counter, rows / 128 + 64))) break;  // (the arena is zero-filled; the last arriver of a launch resets its word)
         }
         if ((rc = A.alloc_t(&p->sat_base, 1024))) break;  // the 8 flag words sit in the middle of a 4 KiB block of their own
         p->sat_flag = p->sat_base + 512;

@@ -165,6 +165,7 @@ struct f5_plan_s {
     // LayerNorm fold: the time grid's table (model-owned, shared), row statistics (mean, rstd) [rows_cap + 256][2], partial sums
     // [D / 64][rows_cap] float2 of the in-place residual epilogues
     FoldTable* fold = nullptr;
+    unsigned* fin_counter = nullptr;  // one ticket word per 128 token rows: in-launch statistics of the non-persistent residual GEMMs (gemm.h); zero between launches
     float *lnf_stats = nullptr, *lnf_stats2 = nullptr, *lnf_partial = nullptr;  // (two statistics tables: a site's pivots are the previous site's means)
     int fold_eval = -1;  // evaluation index of the running net_eval (-1: no table row applies, e.g. f5_dit_forward's per-sample times)
     std::map<std::string, float*> taps;
@@ -218,7 +219,7 @@ int finish_if_pending(f5_plan_s* p);  // completes a deferred sample() before th
 
 
 // ---- eval_common.hip
-extern int g_w_prefetch, g_res_f16, g_ln_defer, g_resid_rmw, g_ln_fold, g_ln_fold_inkernel, g_gemm_pad_rows, g_sync_evals;
+extern int g_w_prefetch, g_res_f16, g_ln_defer, g_resid_rmw, g_ln_fold, g_ln_fold_inkernel, g_ln_fold_fin, g_gemm_pad_rows, g_sync_evals;
 bool plan_res_f16(const f5_plan_s* p);
 GemmParams gp_zero();
 int run_gemm(f5_plan_s* p, const GemmParams& g, int mode, int epi, hipStream_t st);

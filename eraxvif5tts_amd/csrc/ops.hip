@@ -414,7 +414,7 @@ extern "C" int f5_bench_mfma_rate(int random_operands, float* tflops, f5_stream_
     return sync_and_release(a, st, rc);
 }
 
-extern int g_sync_evals, g_attn_persist, g_attn_stagger, g_resid_rmw, g_ln_fold, g_ln_fold_inkernel, g_gemm_pad_rows;
+extern int g_sync_evals, g_attn_persist, g_attn_stagger, g_resid_rmw, g_ln_fold, g_ln_fold_inkernel, g_ln_fold_fin, g_gemm_pad_rows;
 extern int g_conv31_tok;
 extern int g_gemm_bm128, g_gemm_tile, g_gemm_group_sites, g_gemm_reverse_sites;
 extern int g_gemm_split_tail;
@@ -531,6 +531,10 @@ extern "C" int f5_tuning_set(const char* key, int value) {
     }
     if (strcmp(key, "ln_fold_inkernel") == 0) {
         g_ln_fold_inkernel = value != 0;
+        return 0;
+    }
+    if (strcmp(key, "ln_fold_fin") == 0) {
+        g_ln_fold_fin = value != 0;
         return 0;
     }
     if (strcmp(key, "ln_fold") == 0) {

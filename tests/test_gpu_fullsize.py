@@ -181,6 +181,36 @@ def test_in_kernel_row_statistics_equal_the_statistics_kernel():
     assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("B,N", [(1, 600), (1, 1024), (2, 837), (4, 1024)])
+def test_in_launch_row_statistics_equal_the_statistics_kernel(B, N):
+    """Small batches: the in-place residual GEMMs (out-projection, FF2) on the non-persistent schedules finish the LayerNorm fold's row statistics
+    inside the launch (the workgroup that completes a block of token rows last; knob ln_fold_fin, off by default: measured no gain) instead of leaving them to
+    stats_finalize_kernel.  Same arithmetic in the same order (lnf_stats_math.h), so sample() must not change by one bit -- token counts that are
+    and are not multiples of the 128 / 256-row tiles, eager and graph replay (the ticket words must be back at zero after every launch)."""
+    import bench
+    from eraxvif5tts_amd import _lib
+    from eraxvif5tts_amd.model import CFM, DiT
+    lib = _lib.load()
+    torch.manual_seed(4321)
+    model = bench.synth_weights(DiT(**bench.BASE_ARCH, text_num_embeds=bench.VOCAB, mel_dim=100, precision="bf16"), seed=0)
+    cfm = CFM(transformer=model, mel_spec_kwargs={"mel_spec_type": "vocos"}).cuda()
+    cond, text, lens, dur = bench.synth_batch(B, N, "cuda", seed=41)
+    y0 = torch.randn(B, N, 100, generator=torch.Generator().manual_seed(42))
+    kw = dict(cond=cond, text=text, duration=dur, lens=lens, steps=3, cfg_strength=2.0, sway_sampling_coef=-1.0, y0=y0, return_trajectory=False)
+    outs = {}
+    for fin in (0, 1):
+        _lib.check(lib.f5_tuning_set(b"ln_fold_fin", fin))
+        try:
+            outs[fin] = cfm.sample(use_graph=False, **kw)[0].cpu()
+            if fin:
+                for _ in range(2):
+                    assert torch.equal(cfm.sample(use_graph=True, **kw)[0].cpu(), outs[fin])
+        finally:
+            _lib.check(lib.f5_tuning_set(b"ln_fold_fin", 0))
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+    assert model.residual_fallbacks() == 0
+
+
 def test_fold_tables_follow_the_time_grid_across_graphs_and_streams():
     """The LayerNorm-fold tables are per TIME GRID, owned by the model (at most two), shared by its plans, and captured graphs bake their addresses:
     alternate three grids (NFE 3 / 4 / 5: the third evicts the first) with hipGraph replay on two streams, F5TTS_Base width at depth 4 -- every

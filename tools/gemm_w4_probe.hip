@@ -1,0 +1,311 @@
+// gemm_w4_probe.hip -- standalone probe of the round-4 "one wave per SIMD" main loop for the block GEMMs (C = A . W^T, bf16, fp32 accumulate):
+//   256 x 256 x 64 tiles, 4 waves per workgroup (one per SIMD), 128 x 128 outputs per wave held in 256 AccVGPRs, fragments double-buffered in
+//   VGPRs, operands by LDS-DMA (whole 128-byte lines) into TWO 64-KiB stage buffers that are refilled in place two iterations ahead, two
+//   barriers per 64-deep iteration, every non-MFMA instruction placed by hand between the MFMAs (inline asm, hand-counted waits).
+// The vendor library's best kernel for these shapes has this shape (hipBLASLt "MT256x256x64 ... 4 waves"; measured 17 - 22 % faster than the
+// 8-wave staggered kernel of gemm_fast.hip at the four call sites); this file is where the schedule was developed before it moved into the library.
+//   hipcc -O3 --offload-arch=gfx950 tools/gemm_w4_probe.hip -o tools/bin/gemm_w4_probe && tools/bin/gemm_w4_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <type_traits>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+template <int N, int I = 0, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+__device__ __forceinline__ u32x4 pair_swap(bf16x4 a, bf16x4 b) {
+    const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+    const u32x2 s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+    return u32x4{s0[0], s1[0], s0[1], s1[1]};
+}
+__device__ __forceinline__ bf16x4 to_bf16x4(const f32x4& v) { return bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]}; }
+
+// LDS image of one operand of one stage: 256 rows x 128 bytes (64 k), logical 16-byte chunk c of row r at physical chunk c ^ ((r >> 1) & 7):
+// every 16-lane group of a ds_read_b128 fragment read (16 rows, chunks q and q ^ 1) then covers the 16 slots of a 256-byte bank row once.
+// Layout: [A buffer 0][A buffer 1][W buffer 0][W buffer 1], 32 KiB each, so that the buffer and the 16-row tile are immediate offsets.
+constexpr int OPB = 32768;
+
+template <int SCHED>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void w4_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                                                           bf16_t* __restrict__ C, int M, int N, int K, int lda,
+                                                                                           int ldw, int ldc, int tiles_n, int nblocks, int group) {
+    __shared__ __attribute__((aligned(1024))) char smem[4 * OPB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    auto tile_mn = [&](int bid, int& tm0, int& tn0) {  // XCD band + L2 patch order of gemm_fast.hip
+        const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7;
+        const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int gm = group > 0 ? group : 1;
+        const int tiles_m_all = nblocks / tiles_n;
+        const int grp = swz / (gm * tiles_n);
+        const int gsz = min(gm, tiles_m_all - grp * gm);
+        const int rin = swz - grp * gm * tiles_n;
+        const int tile_n = rin / gsz, tile_m = grp * gm + (rin - tile_n * gsz);
+        tm0 = tile_m * 256;
+        tn0 = tile_n * 256;
+    };
+    const int G = gridDim.x;
+    const int my_tiles = (nblocks - (int)blockIdx.x + G - 1) / G;
+    const int nk = K / 64;
+    const int total = my_tiles * nk;
+
+    // ---- DMA: per iteration this wave moves pieces p = wave * 8 + jj (jj = 0..7) of the activation tile and of the weight tile; a piece is 8 rows
+    // x 128 bytes (one instruction: lane l -> row l >> 3, physical chunk l & 7).  Constant per-lane byte offsets, the K position sits in the bases.
+    unsigned voffA[8], voffW[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const int row = (wave * 8 + jj) * 8 + (lane >> 3);
+        const int logical = (lane & 7) ^ ((row >> 1) & 7);
+        voffA[jj] = (unsigned)(row * lda * 2 + logical * 16);
+        voffW[jj] = (unsigned)(row * ldw * 2 + logical * 16);
+    }
+    const char* baseA;  // DMA front: tile row / feature base at the front's K position
+    const char* baseW;
+    int f_tile = blockIdx.x, f_k = 0, f_g = 0;
+    auto front_tile = [&]() {
+        int sm, sn;
+        tile_mn(f_tile, sm, sn);
+        baseA = reinterpret_cast<const char*>(A) + (size_t)sm * lda * 2;
+        baseW = reinterpret_cast<const char*>(W) + (size_t)sn * ldw * 2;
+    };
+    front_tile();
+    const int wdst = wave * 8192;  // this wave's pieces inside an operand buffer
+    auto dma = [&](int ldsdst, unsigned voff, const char* base) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsdst), "v"(voff), "s"(base) : "memory");
+    };
+    auto front_advance = [&]() {
+        ++f_g;
+        baseA += 128;
+        baseW += 128;
+        if (++f_k == nk) {
+            f_k = 0;
+            f_tile += G;
+            if (f_tile < nblocks) front_tile();
+        }
+    };
+    // ---- fragment read addresses (LDS byte addresses; the 16-row tile index and the buffer are immediate offsets)
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const unsigned ra0 = lds0 + (unsigned)((wm * 128 + fr) * 128 + ((fq ^ (fr >> 1)) * 16));  // sub-step 0: chunks 0..3
+    const unsigned ra1 = ra0 ^ 64u;                                                             // sub-step 1: chunks 4..7
+    const unsigned rw0 = lds0 + 2 * OPB + (unsigned)((wn * 128 + fr) * 128 + ((fq ^ (fr >> 1)) * 16));
+    const unsigned rw1 = rw0 ^ 64u;
+
+    f32x4 acc[8][8];  // [feature tile][token tile], AccVGPRs
+    f32x4 fw[2][8], fa[2][8];
+    auto zero_acc = [&]() {
+        static_for<8>([&](auto ic) {
+            static_for<8>([&](auto jc) { acc[decltype(ic)::value][decltype(jc)::value] = f32x4{0.f, 0.f, 0.f, 0.f}; });
+        });
+    };
+#define DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+    // read fragment e (0..7: weight tiles, 8..15: token tiles) of sub-step S from buffer X
+    auto rd = [&](auto sc, auto xc, auto ec) {
+        constexpr int S = decltype(sc)::value, X = decltype(xc)::value, e = decltype(ec)::value;
+        (void)fw; (void)fa; (void)ra0; (void)ra1; (void)rw0; (void)rw1;  // (asm operands alone do not capture inside a generic lambda)
+        if constexpr (e < 8) {
+            if constexpr (S == 0) DSR(fw[0][e], rw0, X * OPB + e * 2048); else DSR(fw[1][e], rw1, X * OPB + e * 2048);
+        } else {
+            if constexpr (S == 0) DSR(fa[0][e - 8], ra0, X * OPB + (e - 8) * 2048); else DSR(fa[1][e - 8], ra1, X * OPB + (e - 8) * 2048);
+        }
+    };
+    // one 64-deep iteration on buffer X.  ISSUE: the DMA front still has stages to request; WAITV: the next iteration's stage must be waited for
+    // (not in a tile's first iteration: everything requested before the epilogue was waited for there).
+    auto body = [&](auto xc, auto issuec, auto waitc) {
+        constexpr int X = decltype(xc)::value;
+        constexpr bool ISSUE = decltype(issuec)::value, WAITV = decltype(waitc)::value;
+        static_for<128>([&](auto nc) {
+            (void)acc; (void)fw; (void)fa;
+            constexpr int n = decltype(nc)::value;
+            constexpr int s = n / 64, i = (n % 64) / 8, j = n % 8;
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fw[s][i]), "v"(fa[s][j]));
+            if constexpr (n < 48 && n % 3 == 0) rd(std::integral_constant<int, 1>{}, xc, std::integral_constant<int, n / 3>{});
+            if constexpr (n == 49) {  // B1: every wave is done with buffer X
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            if constexpr (ISSUE && n >= 50 && n < 98 && (n - 50) % 3 == 0) {
+                constexpr int pc = (n - 50) / 3;
+                if constexpr (pc < 8)
+                    dma(X * OPB + wdst + pc * 1024, voffA[pc], baseA);
+                else
+                    dma(2 * OPB + X * OPB + wdst + (pc - 8) * 1024, voffW[pc - 8], baseW);
+            }
+            if constexpr (n == 100) {  // B2: the other buffer (next iteration's stage) has landed for everyone
+                if constexpr (WAITV && ISSUE)
+                    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+                else if constexpr (WAITV)
+                    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                else
+                    asm volatile("s_barrier" ::: "memory");
+            }
+            if constexpr (n >= 102 && n < 126) {
+                constexpr int a = n - 102;  // 24 slots, 16 reads: slots 0,1,3,4,6,7,...
+                if constexpr (a % 3 != 2) rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 1 - X>{}, std::integral_constant<int, a - a / 3>{});
+            }
+            if constexpr (n == 127) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        });
+        if constexpr (ISSUE) front_advance();
+    };
+
+    // ---- prologue: stages 0 and 1 requested, stage 0 landed, first fragments read
+    auto issue_all = [&](int X) {
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc) dma(X * OPB + wdst + pc * 1024, voffA[pc], baseA);
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc) dma(2 * OPB + X * OPB + wdst + pc * 1024, voffW[pc], baseW);
+    };
+    issue_all(0);
+    front_advance();
+    issue_all(1);
+    front_advance();
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    static_for<16>([&](auto ec) { rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, ec); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    zero_acc();
+
+    int m0, n0;
+    tile_mn(blockIdx.x, m0, n0);
+    auto epilogue = [&]() {
+        bf16_t* orow = C + (size_t)(m0 + wm * 128 + fr) * ldc + n0 + wn * 128 + 16 * (fq & 1) + 8 * (fq >> 1);
+        static_for<8>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            __builtin_amdgcn_sched_barrier(0);  // (keeps the accumulator reads of later token tiles from being hoisted: register pressure)
+            static_for<4>([&](auto hc) {
+                constexpr int i = decltype(hc)::value * 2;
+                // (an empty volatile asm on the AccVGPR value: the AGPR -> VGPR copies of the C++ use below cannot be hoisted above it, i.e. the
+                //  compiler cannot read all 256 accumulators into VGPRs at the top of the epilogue and spill)
+                asm volatile("" : "+a"(acc[i][j]));
+                asm volatile("" : "+a"(acc[i + 1][j]));
+                const u32x4 q = pair_swap(to_bf16x4(acc[i][j]), to_bf16x4(acc[i + 1][j]));
+                *reinterpret_cast<u32x4*>(orow + (size_t)16 * j * ldc + 32 * (i / 2)) = q;
+            });
+        });
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    using X0 = std::integral_constant<int, 0>;
+    using X1 = std::integral_constant<int, 1>;
+    // a tile: nk iterations (nk even, >= 4), buffer = kt & 1; only the last two iterations of the last tile request nothing
+    for (int t = 0; t < my_tiles; ++t) {
+        const bool last = t + 1 == my_tiles;
+        if (t == 0)
+            body(X0{}, T{}, T{});  // (the very first iteration waits: stage 1 was requested just now)
+        else
+            body(X0{}, T{}, F{});
+        body(X1{}, T{}, T{});
+        const int kend = last ? nk - 2 : nk;
+        for (int kt = 2; kt < kend; kt += 2) {
+            body(X0{}, T{}, T{});
+            body(X1{}, T{}, T{});
+        }
+        if (last) {
+            body(X0{}, F{}, T{});
+            body(X1{}, F{}, T{});
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stages requested ahead have landed; only stores follow
+        epilogue();
+        zero_acc();
+        if (!last) tile_mn(blockIdx.x + (t + 1) * G, m0, n0);
+    }
+}
+
+__global__ void ref_rows(const bf16_t* A, const bf16_t* W, float* out, const int* rows, int nrows, int N, int K, int lda, int ldw) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (n >= N || r >= nrows) return;
+    const bf16_t* a = A + (size_t)rows[r] * lda;
+    const bf16_t* w = W + (size_t)n * ldw;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += (float)a[k] * (float)w[k];
+    out[(size_t)r * N + n] = s;
+}
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
+
+int main(int argc, char** argv) {
+    struct Shape { const char* name; int M, N, K; };
+    const Shape shapes[] = {{"small", 1024, 512, 512}, {"qkv", 65536, 3072, 1024}, {"ff1", 65536, 2048, 1024}, {"ff2", 65536, 1024, 2048}, {"out", 65536, 1024, 1024}};
+    int ncu = 256;
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    ncu = prop.multiProcessorCount & ~7;
+    for (const Shape& sh : shapes) {
+        const int M = sh.M, N = sh.N, K = sh.K;
+        std::vector<uint16_t> hA((size_t)M * K), hW((size_t)N * K);
+        uint32_t st = 12345u;
+        auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.0f - 0.5f; };
+        for (auto& v : hA) v = f2bf(rnd());
+        for (auto& v : hW) v = f2bf(rnd());
+        bf16_t *dA, *dW, *dC;
+        CK(hipMalloc(&dA, hA.size() * 2));
+        CK(hipMalloc(&dW, hW.size() * 2));
+        CK(hipMalloc(&dC, (size_t)M * N * 2));
+        CK(hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemset(dC, 0xff, (size_t)M * N * 2));
+        const int tiles_m = M / 256, tiles_n = N / 256, nblocks = tiles_m * tiles_n;
+        const int grid = nblocks < ncu ? nblocks : ncu;
+        hipLaunchKernelGGL(w4_kernel<0>, dim3(grid), dim3(256), 0, 0, dA, dW, dC, M, N, K, K, K, N, tiles_n, nblocks, 8);
+        CK(hipGetLastError());
+        CK(hipDeviceSynchronize());
+        // check sampled rows
+        const int nrows = 24;
+        std::vector<int> rows(nrows);
+        for (int r = 0; r < nrows; ++r) rows[r] = (int)(((long long)r * 2654435761LL) % M);
+        rows[0] = 0; rows[1] = M - 1; rows[2] = 255; rows[3] = 256 % M;
+        int* dRows; float* dRef;
+        CK(hipMalloc(&dRows, nrows * 4));
+        CK(hipMalloc(&dRef, (size_t)nrows * N * 4));
+        CK(hipMemcpy(dRows, rows.data(), nrows * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(ref_rows, dim3((N + 255) / 256, nrows), dim3(256), 0, 0, dA, dW, dRef, dRows, nrows, N, K, K, K);
+        CK(hipDeviceSynchronize());
+        std::vector<float> ref((size_t)nrows * N);
+        std::vector<uint16_t> got(N);
+        CK(hipMemcpy(ref.data(), dRef, ref.size() * 4, hipMemcpyDeviceToHost));
+        double maxerr = 0, maxref = 0;
+        for (int r = 0; r < nrows; ++r) {
+            CK(hipMemcpy(got.data(), (uint16_t*)dC + (size_t)rows[r] * N, N * 2, hipMemcpyDeviceToHost));
+            for (int n = 0; n < N; ++n) {
+                const double e = fabs((double)bf2f(got[n]) - ref[(size_t)r * N + n]);
+                if (!(e <= maxerr)) maxerr = e;
+                if (fabs(ref[(size_t)r * N + n]) > maxref) maxref = fabs(ref[(size_t)r * N + n]);
+            }
+        }
+        // timing
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        float best = 1e9f;
+        for (int rnd2 = 0; rnd2 < 3; ++rnd2) {
+            CK(hipEventRecord(e0));
+            for (int it = 0; it < 10; ++it)
+                hipLaunchKernelGGL(w4_kernel<0>, dim3(grid), dim3(256), 0, 0, dA, dW, dC, M, N, K, K, K, N, tiles_n, nblocks, 8);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms / 10 < best) best = ms / 10;
+        }
+        printf("%s M=%d N=%d K=%d: %.1f us = %.0f TF | max abs err %.4g (max |ref| %.3g)%s\n", sh.name, M, N, K, best * 1e3, 2.0 * M * N * K / best / 1e9, maxerr, maxref,
+               maxerr <= 0.02 * maxref + 1e-3 ? "" : "  <-- MISMATCH");
+        fflush(stdout);
+        (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dC); (void)hipFree(dRows); (void)hipFree(dRef);
+    }
+    return 0;
+}
