@@ -1031,8 +1031,8 @@ int g_gemm_split_tail = 0;  // tuning knob ("gemm_split_tail"): 1 = M % 256 != 0
 static int persist_grid() { return gemm_persist_grid(); }
 #endif
 
-template <int BN, int WM, int MODE, int EPI, bool LNF = false> static int launch_fast(const GemmParams& p0, hipStream_t stream) {
-    GemmParams p = p0;
+// tile walk of a launch: L2 patch height and direction per block call site (also used by the one-wave-per-SIMD kernel, gemm_w4.hip)
+static void apply_site_knobs(GemmParams& p) {
     // L2 patch height: 8 token tiles per XCD patch.  (Until late in round 3 the 8-feature-tile projection -- FF1, N = 2048 -- took 16: +3 % on
     // that launch in isolation, but in situ the FF2 launch behind it reads FF1's output and runs 277 -> 267 us when FF1 wrote it in patches of
     // 8 like its own: same-box A/B x 3 at C2, 30 408 -> 30 575 mel-frames/s.)
@@ -1049,6 +1049,11 @@ template <int BN, int WM, int MODE, int EPI, bool LNF = false> static int launch
             if (v > 0) p.tile_group = v;
         }
     }
+}
+
+template <int BN, int WM, int MODE, int EPI, bool LNF = false> static int launch_fast(const GemmParams& p0, hipStream_t stream) {
+    GemmParams p = p0;
+    apply_site_knobs(p);
     p.lean_epi = g_gemm_lean;
     p.clk = g_gemm_clk_buf;
     constexpr int BMv = (8 / (BN / 64)) * WM;  // token rows of a tile (see the kernel)
@@ -1111,6 +1116,8 @@ template <int BN, int WM, int MODE, int EPI, bool LNF = false> static int launch
 
 #ifndef F5_LNF_TU
 int launch_gemm_fast_lnf(const GemmParams& p, int epi, int bm, int bn, hipStream_t stream);  // gemm_fast_lnf.hip
+bool gemm_w4_ok(const GemmParams& p, int mode, int epi);                                     // gemm_w4.hip
+int launch_gemm_w4(const GemmParams& p, int epi, hipStream_t stream);
 bool gemm_fast_supported(const GemmParams& p, int precision, int mode, int epi) {
     if (precision != F5_PREC_BF16 || p.M <= 0 || p.N <= 0) return false;
     if (p.lda & 7) return false;
@@ -1185,6 +1192,11 @@ int launch_gemm_fast(const GemmParams& p, int mode, int epi, hipStream_t stream)
         if (epi == EPI_STORE_T) return launch_fast<64, 32, GEMM_CONV31, EPI_STORE_T>(p, stream);
         if (epi == EPI_GATE_T) return launch_fast<64, 32, GEMM_CONV31, EPI_GATE_T>(p, stream);
         return f5_fail(F5_EINVAL, "gemm_fast(conv31): unsupported epilogue %d", epi);
+    }
+    if (g_gemm_variant != 0 && g_gemm_persist && gemm_w4_ok(p, mode, epi)) {  // large whole-tile block linears: one wave per SIMD (gemm_w4.hip)
+        GemmParams q = p;
+        apply_site_knobs(q);
+        return launch_gemm_w4(q, epi, stream);
     }
     int bn, bm;
     gemm_fast_tile(p, &bm, &bn);

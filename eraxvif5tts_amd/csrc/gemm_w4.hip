@@ -1,0 +1,468 @@
+// gemm_w4.hip -- the block linears of a large batch on ONE wave per SIMD (round 4, late):  out[M,N] = epilogue(A[M,K] . W[N,K]^T), fp32 accumulate.
+//
+// Why a second tuned kernel.  Round 4 timed the vendor library at the four block call sites of C2 for the first time (tools/hipblaslt_ref.py): its
+// hand-written 256 x 256 x 64 kernel with FOUR waves per workgroup was 17 - 22 % faster than gemm_fast.hip's 8-wave staggered kernel in isolation.
+// The difference is the per-wave tile: 128 x 128 outputs per wave need 16 ds_read_b128 per 64 MFMAs, the 128 x 64 tile of the 8-wave kernel 12 per
+// 32 -- a third less LDS traffic per FLOP -- and whole 128-byte lines per LDS-DMA row instead of half lines.  Round 1 had tried this tile shape with
+// compiler-scheduled code and lost (every stall of a lone wave is exposed); here every non-MFMA instruction of the main loop is PLACED BY HAND
+// between the MFMAs (inline asm, hand-counted s_waitcnt), which is what makes the shape pay: tools/gemm_w4_probe.hip developed the schedule
+// (8192^3: 1 490 TFLOP/s against 1 320 for the vendor kernel on the same box; LDS bank conflicts 0).
+//
+// Structure:
+//   * persistent grid, one 256-thread workgroup per CU, 256 x 256 output tile, wave w owns tokens (w >> 1) * 128.., features (w & 1) * 128..;
+//     256 accumulator registers per lane in the AccVGPR file, two fragment sets (2 x 64 VGPRs) so that the reads of a 32-deep sub-step fly
+//     under the MFMAs of the one before;
+//   * operands by LDS-DMA (global_load_lds_dwordx4, 8 rows x 128 bytes per instruction) into TWO 64-KiB stage buffers (64 k each) that are
+//     refilled IN PLACE two iterations ahead: barrier B1 (every wave has read the buffer) -> 16 requests per wave spread over the MFMAs;
+//     barrier B2 behind a counted vmcnt (the other buffer has landed) -> the next iteration's first fragments.  The DMA front crosses tile
+//     boundaries, so a tile's first two stages land before / under the previous tile's epilogue;
+//   * LDS image: row r (128 bytes), logical 16-byte chunk c at physical chunk c ^ ((r >> 1) & 7) -- applied on the DMA source address and on the
+//     read address -- every 16-lane group of a ds_read_b128 covers the 16 slots of the 256-byte bank row once (SQ_LDS_BANK_CONFLICT = 0);
+//   * same MFMA (weights on the row index), same K order, same start value (bias, or 0 under the LayerNorm fold) and the same epilogue arithmetic
+//     as gemm_fast.hip's persistent build: a wave's 128 features are treated as two 64-feature halves = two "waves" of that kernel, so the output
+//     bits do not depend on which of the two kernels a launch takes (tests/test_gpu_ops.py::test_w4_kernel_equals_the_8_wave_kernel).
+// Launch conditions (launch_gemm_w4_ok): bf16 / fp16-fold operands, M % 256 == 0, N % 256 == 0, K % 128 == 0, K >= 256, the lean operand forms
+// of the persistent 8-wave build, at least one tile per CU.
+#include "gemm_tile.h"
+#include "lnf_stats_math.h"
+
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int OPB = 32768;          // one operand of one stage: 256 rows x 128 bytes
+constexpr int EPI_LDS = 4 * OPB;    // epilogue operands of the LayerNorm fold: 4 waves x 2 KiB behind the stage buffers
+
+template <int EPI, bool LNF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_w4_kernel(GemmParams p, int tiles_n, int nblocks) {
+    static_assert(EPI == EPI_STORE_T || EPI == EPI_ROPE_T || EPI == EPI_RESID, "block linears only");
+    static_assert(!LNF || EPI != EPI_RESID, "LayerNorm fold: QKV (+ RoPE) and FF1 (+ GELU)");
+    __shared__ __attribute__((aligned(1024))) char smem[4 * OPB + 4 * 2048];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    auto tile_mn = [&](int bid, int& tm0, int& tn0) {  // XCD band + L2 patch order, as gemm_fast.hip
+        const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7;
+        int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        if (p.tile_reverse) swz = nblocks - 1 - swz;
+        const int gm = p.tile_group > 0 ? p.tile_group : 1;
+        const int tiles_m_all = nblocks / tiles_n;
+        const int grp = swz / (gm * tiles_n);
+        const int gsz = min(gm, tiles_m_all - grp * gm);
+        const int rin = swz - grp * gm * tiles_n;
+        const int tile_n = rin / gsz, tile_m = grp * gm + (rin - tile_n * gsz);
+        tm0 = tile_m * 256;
+        tn0 = tile_n * 256;
+    };
+    const int G = gridDim.x;
+    const int my_tiles = (nblocks - (int)blockIdx.x + G - 1) / G;
+    const int nk = p.K / 64;
+
+    // ---- DMA: per iteration this wave moves pieces wave * 8 + jj (jj = 0..7) of the activation tile and of the weight tile; a piece is 8 rows x 128
+    // bytes (lane l -> row l >> 3, physical chunk l & 7).  Per-lane byte offsets are constant, the tile and the K position sit in two scalar bases.
+    unsigned voffA[8], voffW[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const int row = (wave * 8 + jj) * 8 + (lane >> 3);
+        const int logical = (lane & 7) ^ ((row >> 1) & 7);
+        voffA[jj] = (unsigned)(row * p.lda * 2 + logical * 16);
+        voffW[jj] = (unsigned)(row * p.ldw * 2 + logical * 16);
+    }
+    const char* baseA;
+    const char* baseW;
+    int f_tile = blockIdx.x, f_k = 0;
+    auto front_tile = [&]() {
+        int sm, sn;
+        tile_mn(f_tile, sm, sn);
+        baseA = static_cast<const char*>(p.A) + (size_t)sm * p.lda * 2;
+        baseW = static_cast<const char*>(p.W) + (size_t)sn * p.ldw * 2;
+    };
+    front_tile();
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const int wdst = (int)lds0 + wave * 8192;  // this wave's pieces inside an operand buffer
+    // (s_nop: one wait state between the scalar write of M0 and the LDS-DMA that reads it; the hazard recogniser does not look inside an asm)
+    auto dma16w = [&](int ldsdst, unsigned voff, const char* base) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsdst), "v"(voff), "s"(base) : "memory");
+    };
+    auto dma4w = [&](int ldsdst, unsigned voff, const void* base) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(ldsdst), "v"(voff), "s"(base) : "memory");
+    };
+    auto front_advance = [&]() {
+        baseA += 128;
+        baseW += 128;
+        if (++f_k == nk) {
+            f_k = 0;
+            f_tile += G;
+            if (f_tile < nblocks) front_tile();
+        }
+    };
+    // ---- fragment read addresses (LDS byte addresses; the 16-row tile index and the buffer are immediate offsets).  Layout: [A buffer 0][A buffer 1]
+    // [W buffer 0][W buffer 1]
+    const unsigned ra0 = lds0 + (unsigned)((wm * 128 + fr) * 128 + ((fq ^ (fr >> 1)) * 16));  // sub-step 0: chunks 0..3
+    const unsigned ra1 = ra0 ^ 64u;                                                             // sub-step 1: chunks 4..7
+    const unsigned rw0 = lds0 + 2 * OPB + (unsigned)((wn * 128 + fr) * 128 + ((fq ^ (fr >> 1)) * 16));
+    const unsigned rw1 = rw0 ^ 64u;
+
+    f32x4 acc[8][8];  // [feature tile][token tile], AccVGPRs
+    f32x4 fw[2][8], fa[2][8];
+#define W4_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+    auto rd = [&](auto sc, auto xc, auto ec) {  // fragment e (0..7 weight tiles, 8..15 token tiles) of sub-step S from buffer X
+        constexpr int S = decltype(sc)::value, X = decltype(xc)::value, e = decltype(ec)::value;
+        (void)fw; (void)fa; (void)ra0; (void)ra1; (void)rw0; (void)rw1;  // (asm operands alone do not capture inside a generic lambda)
+        if constexpr (e < 8) {
+            if constexpr (S == 0) W4_DSR(fw[0][e], rw0, X * OPB + e * 2048); else W4_DSR(fw[1][e], rw1, X * OPB + e * 2048);
+        } else {
+            if constexpr (S == 0) W4_DSR(fa[0][e - 8], ra0, X * OPB + (e - 8) * 2048); else W4_DSR(fa[1][e - 8], ra1, X * OPB + (e - 8) * 2048);
+        }
+    };
+    // One 64-deep iteration on buffer X: 128 MFMAs, and between them -- RD1: the 16 fragment reads of sub-step 1 (slots 0, 2, .. 30); B1 behind slot
+    // 40: lgkmcnt(0) + barrier = every wave is done with buffer X; the 16 DMA requests of the stage two iterations ahead into buffer X (slots 42, 45,
+    // .. 87); B2 behind slot 86: counted vmcnt (this iteration's 15 requests so far may fly, everything older has landed) + barrier = the other
+    // buffer is complete; RD0: the next iteration's sub-step-0 fragments from it (slots 88, 90, .. 118); lgkmcnt(0) behind the last MFMA.
+    // ISSUE false: the last two iterations of the last tile request nothing.  WAITV false: a tile's first iteration after an epilogue (everything
+    // requested before the epilogue was waited for in front of it; a wait here would also wait for the epilogue's stores: they share vmcnt).
+    auto body = [&](auto xc, auto issuec, auto waitc) {
+        constexpr int X = decltype(xc)::value;
+        constexpr bool ISSUE = decltype(issuec)::value, WAITV = decltype(waitc)::value;
+        constexpr int R1S = 2, B1P = 40, D0 = 42, DS = 3, B2P = 86, R0 = 88, R0S = 2;
+        static_for<128>([&](auto nc) {
+            (void)acc; (void)fw; (void)fa; (void)voffA; (void)voffW; (void)baseA; (void)baseW;
+            constexpr int n = decltype(nc)::value;
+            constexpr int s = n / 64, i = (n % 64) / 8, j = n % 8;
+            if constexpr (LNF)
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fw[s][i]), "v"(fa[s][j]));
+            else
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fw[s][i]), "v"(fa[s][j]));
+            if constexpr (n < 16 * R1S && n % R1S == 0) rd(std::integral_constant<int, 1>{}, xc, std::integral_constant<int, n / R1S>{});
+            if constexpr (n == B1P) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if constexpr (ISSUE && n >= D0 && n < D0 + 16 * DS && (n - D0) % DS == 0) {
+                constexpr int pc = (n - D0) / DS;
+                if constexpr (pc < 8)
+                    dma16w(X * OPB + wdst + pc * 1024, voffA[pc], baseA);
+                else
+                    dma16w(2 * OPB + X * OPB + wdst + (pc - 8) * 1024, voffW[pc - 8], baseW);
+            }
+            if constexpr (n == B2P) {
+                constexpr int issued = !ISSUE ? 0 : (B2P - D0) / DS + 1;  // this iteration's requests so far
+                if constexpr (WAITV)
+                    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(issued) : "memory");
+                else
+                    asm volatile("s_barrier" ::: "memory");
+            }
+            if constexpr (n >= R0 && n < R0 + 16 * R0S && (n - R0) % R0S == 0)
+                rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 1 - X>{}, std::integral_constant<int, (n - R0) / R0S>{});
+            if constexpr (n == 127) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        });
+        if constexpr (ISSUE) front_advance();
+    };
+
+    // ---- per-tile epilogue operands
+    int m0, n0;
+    tile_mn(blockIdx.x, m0, n0);
+    char* const lnf_lds = smem + EPI_LDS + wave * 2048;  // LNF: c1[128] | c2[128] | (mean, rstd)[128 rows] of this wave, by LDS-DMA at the start of a tile
+    [[maybe_unused]] auto stage_lnf = [&]() {
+        const int ldst = (int)lds0 + EPI_LDS + wave * 2048;
+        const unsigned nb = (unsigned)(n0 + wn * 128 + lane) * 4u;
+        dma4w(ldst, nb, p.lnf_c1);
+        dma4w(ldst + 256, nb + 256u, p.lnf_c1);
+        dma4w(ldst + 512, nb, p.lnf_c2);
+        dma4w(ldst + 768, nb + 256u, p.lnf_c2);
+        dma16w(ldst + 1024, (unsigned)((m0 + wm * 128 + 2 * lane) * 8), reinterpret_cast<const char*>(p.lnf_stats));  // lane l: rows 2l, 2l + 1
+    };
+    [[maybe_unused]] auto lnf_apply = [&](const f32x4& a, int i, int j) {  // i: feature tile 0..7 of the wave, j: token tile
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(lnf_lds + (i * 16 + 4 * fq) * 4);
+        const f32x4 c2 = *reinterpret_cast<const f32x4*>(lnf_lds + 512 + (i * 16 + 4 * fq) * 4);
+        const f32x2 st = *reinterpret_cast<const f32x2*>(lnf_lds + 1024 + (j * 16 + fr) * 8);
+        return epi_lnf4(a, st[0], st[1], c1, c2);
+    };
+    auto load_bias = [&](int tn0, f32x4 (&dst)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[i] = *reinterpret_cast<const f32x4*>(p.bias + tn0 + wn * 128 + i * 16 + 4 * fq);
+    };
+    auto acc_from = [&](const f32x4 (&b4)[8]) {  // every accumulator starts from its feature's bias (gemm_fast.hip: init_acc)
+        static_for<8>([&](auto ic) {
+            static_for<8>([&](auto jc) { acc[decltype(ic)::value][decltype(jc)::value] = b4[decltype(ic)::value]; });
+        });
+    };
+    // (an empty volatile asm on the AccVGPR value in front of every C++ use: the AGPR -> VGPR copies cannot be hoisted above it, so the compiler
+    //  cannot read all 256 accumulators into VGPRs at the top of the epilogue and spill)
+#define W4_ACC(i, j) ([&]() -> f32x4 { asm volatile("" : "+a"(acc[i][j])); return acc[i][j]; }())
+
+    // ---- store-only epilogue of one 64-feature half (= lean_epilogue of gemm_fast.hip for one of its waves)
+    [[maybe_unused]] auto store_half = [&](auto hc, auto actc) {
+        constexpr int h = decltype(hc)::value, ACT = decltype(actc)::value;
+        const int nb = n0 + wn * 128 + h * 64;
+        bf16_t* orow = reinterpret_cast<bf16_t*>(p.out_t) + (size_t)(m0 + wm * 128 + fr) * p.ldo + nb + 16 * (fq & 1) + 8 * (fq >> 1);
+        const size_t jstride = (size_t)16 * p.ldo;
+        [[maybe_unused]] bool rope_wave = false;
+        [[maybe_unused]] f32x4 rp[2][4];
+        [[maybe_unused]] int pos0 = 0;
+        auto load_rope = [&](auto jc, f32x4 (&dst)[4]) {
+            constexpr int j = decltype(jc)::value;
+            int pos = pos0 + 16 * j;
+            pos -= pos >= p.rows_per_batch ? p.rows_per_batch : 0;  // rows_per_batch >= 128 (launcher)
+            const float* t = p.rope + (size_t)pos * 64 + 4 * fq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const f32x4*>(t + 16 * i);
+        };
+        if constexpr (EPI == EPI_ROPE_T) {
+            const int part = nb / p.rope_inner;
+            rope_wave = part < 2 && ((nb - part * p.rope_inner) >> 6) < p.rope_heads;
+            pos0 = (p.row0 + m0 + wm * 128 + fr) % p.rows_per_batch;
+            if (rope_wave) load_rope(std::integral_constant<int, 0>{}, rp[0]);
+        }
+        static_for<8>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (EPI == EPI_ROPE_T && j + 1 < 8) {
+                if (rope_wave) load_rope(std::integral_constant<int, j + 1>{}, rp[(j + 1) & 1]);
+            }
+            f32x4 vals[4];
+            static_for<4>([&](auto ic) {
+                constexpr int ii = decltype(ic)::value, i = h * 4 + ii;
+                f32x4 v = W4_ACC(i, j);
+                if constexpr (LNF) v = lnf_apply(v, i, j);
+                if constexpr (ACT == ACT_GELU_TANH) v = epi_gelu_tanh4(v);
+                if constexpr (EPI == EPI_ROPE_T) {
+                    if (rope_wave) v = epi_rope4(v, rp[j & 1][ii]);
+                }
+                vals[ii] = v;
+            });
+            const u32x4 q0 = pair_swap(to_bf16x4(vals[0]), to_bf16x4(vals[1]));
+            const u32x4 q1 = pair_swap(to_bf16x4(vals[2]), to_bf16x4(vals[3]));
+            bf16_t* o = orow + j * jstride;
+            *reinterpret_cast<u32x4*>(o) = q0;
+            *reinterpret_cast<u32x4*>(o + 32) = q1;
+        });
+    };
+    // ---- in-place update of the fp16 residual stream by one 64-feature half (= lean_resid_f16 of gemm_fast.hip for one of its waves), with the
+    // LayerNorm fold's partial row statistics of the values just stored
+    [[maybe_unused]] auto emit_stats = [&](int nb, int m, float pivot, const f32x4& h0, const f32x4& h1, const f32x4& h2, const f32x4& h3) {
+        const f32x4 pv{pivot, pivot, pivot, pivot};
+        const f32x4 d0 = h0 - pv, d1 = h1 - pv, d2 = h2 - pv, d3 = h3 - pv;
+        const f32x4 a = (d0 + d1) + (d2 + d3);
+        const f32x4 q = __builtin_elementwise_fma(d3, d3, __builtin_elementwise_fma(d2, d2, __builtin_elementwise_fma(d1, d1, d0 * d0)));
+        const float s1 = (a[0] + a[1]) + (a[2] + a[3]), s2 = (q[0] + q[1]) + (q[2] + q[3]);
+        float a0 = s1, b0 = s2;  // (inline asm: gemm_fast.hip, emit_stats)
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a0), "+v"(b0));
+        float t = a0 + b0, z = 0.0f;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(t), "+v"(z));
+        const float tot = t + z;
+        if (fq < 2) p.stats_out[((size_t)(nb >> 6) * p.stats_ld + m) * 2 + fq] = tot;
+    };
+    [[maybe_unused]] auto resid_half = [&](auto hc, const f32x4 (&gate4)[8], unsigned keepbits) {
+        constexpr int h = decltype(hc)::value;
+        const int nb = n0 + wn * 128 + h * 64;
+        const size_t row0 = (size_t)(m0 + wm * 128 + fr);
+        _Float16* hrow = reinterpret_cast<_Float16*>(p.out_f) + row0 * p.ldof + nb + 16 * (fq & 1) + 8 * (fq >> 1);
+        u32x4 adA[2], adB[2];
+        auto load_x = [&](auto jc, u32x4 (&dst)[2]) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            dst[0] = *reinterpret_cast<const u32x4*>(hrow + (size_t)16 * j * p.ldof);
+            dst[1] = *reinterpret_cast<const u32x4*>(hrow + (size_t)16 * j * p.ldof + 32);
+        };
+        auto widen_h = [](unsigned lo, unsigned hi) __attribute__((always_inline)) {
+            const f16x4_t hv = __builtin_bit_cast(f16x4_t, u32x2{lo, hi});
+            return f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+        };
+        auto to_h = [](const f32x4& v) __attribute__((always_inline)) {
+            f16x4_t hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hv[e] = (_Float16)__builtin_amdgcn_fmed3f(v[e], -65504.0f, 65504.0f);
+            return __builtin_bit_cast(bf16x4, hv);
+        };
+        auto h_round4 = [](const f32x4& v) {
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = (float)(_Float16)__builtin_amdgcn_fmed3f(v[e], -65504.0f, 65504.0f);
+            return r;
+        };
+        load_x(std::integral_constant<int, 0>{}, adA);
+        [[maybe_unused]] float piv[8];
+        if (p.stats_out) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) piv[j] = p.stats_pivot ? p.stats_pivot[(row0 + (size_t)16 * j) * 2] : 0.0f;
+        }
+        static_for<8>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (j + 1 < 8) {
+                if constexpr ((j + 1) & 1)
+                    load_x(std::integral_constant<int, j + 1>{}, adB);
+                else
+                    load_x(std::integral_constant<int, j + 1>{}, adA);
+            }
+            const bool keep = (keepbits >> j) & 1u;
+            f32x4 x0, x1, x2, x3;
+            {
+                const u32x4 q = (j & 1) ? adB[0] : adA[0];
+                const u32x2 s0 = __builtin_amdgcn_permlane16_swap(q[0], q[2], false, false);
+                const u32x2 s1 = __builtin_amdgcn_permlane16_swap(q[1], q[3], false, false);
+                x0 = widen_h(s0[0], s1[0]);
+                x1 = widen_h(s0[1], s1[1]);
+            }
+            {
+                const u32x4 q = (j & 1) ? adB[1] : adA[1];
+                const u32x2 s0 = __builtin_amdgcn_permlane16_swap(q[0], q[2], false, false);
+                const u32x2 s1 = __builtin_amdgcn_permlane16_swap(q[1], q[3], false, false);
+                x2 = widen_h(s0[0], s1[0]);
+                x3 = widen_h(s0[1], s1[1]);
+            }
+            const f32x4 a0 = W4_ACC(h * 4 + 0, j), a1 = W4_ACC(h * 4 + 1, j), a2 = W4_ACC(h * 4 + 2, j), a3 = W4_ACC(h * 4 + 3, j);
+            const f32x4 v0 = keep ? epi_axpy4(a0, gate4[h * 4 + 0], x0) : x0;
+            const f32x4 v1 = keep ? epi_axpy4(a1, gate4[h * 4 + 1], x1) : x1;
+            const f32x4 v2 = keep ? epi_axpy4(a2, gate4[h * 4 + 2], x2) : x2;
+            const f32x4 v3 = keep ? epi_axpy4(a3, gate4[h * 4 + 3], x3) : x3;
+            const size_t jo = (size_t)16 * j;
+            *reinterpret_cast<u32x4*>(hrow + jo * p.ldof) = pair_swap(to_h(v0), to_h(v1));
+            *reinterpret_cast<u32x4*>(hrow + jo * p.ldof + 32) = pair_swap(to_h(v2), to_h(v3));
+            if (p.stats_out) emit_stats(nb, (int)row0 + 16 * j, piv[j], h_round4(v0), h_round4(v1), h_round4(v2), h_round4(v3));
+        });
+    };
+
+    // ---- prologue: stages 0 and 1 requested, stage 0 landed, first fragments read
+    auto issue_all = [&](int X) {
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc) dma16w(X * OPB + wdst + pc * 1024, voffA[pc], baseA);
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc) dma16w(2 * OPB + X * OPB + wdst + pc * 1024, voffW[pc], baseW);
+    };
+    issue_all(0);
+    front_advance();
+    issue_all(1);
+    front_advance();
+    if constexpr (LNF) stage_lnf();
+    f32x4 bstart[8];
+    if constexpr (LNF) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bstart[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+        load_bias(n0, bstart);
+    }
+    acc_from(bstart);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LNF ? 21 : 16) : "memory");  // stage 0 has landed for everyone
+    static_for<16>([&](auto ec) { rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, ec); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    using T = std::true_type;
+    using F = std::false_type;
+    using X0 = std::integral_constant<int, 0>;
+    using X1 = std::integral_constant<int, 1>;
+    // a tile: nk iterations (nk even, >= 4), buffer = iteration & 1
+    for (int t = 0; t < my_tiles; ++t) {
+        const bool last = t + 1 == my_tiles;
+        if (t == 0)
+            body(X0{}, T{}, T{});  // (the very first iteration waits: stage 1 was requested just now)
+        else
+            body(X0{}, T{}, F{});
+        body(X1{}, T{}, T{});
+        const int kend = last ? nk - 2 : nk;
+        for (int kt = 2; kt < kend; kt += 2) {
+            body(X0{}, T{}, T{});
+            body(X1{}, T{}, T{});
+        }
+        if (last) {
+            body(X0{}, F{}, T{});
+            body(X1{}, F{}, T{});
+        }
+        // the epilogue's per-tile operands and the NEXT tile's accumulator start are requested before the stores and waited for while only
+        // loads are in flight (loads and stores share vmcnt: a wait behind the stores would hold the wave until they are acknowledged)
+        int nm0 = m0, nn0 = n0;
+        if (!last) tile_mn(blockIdx.x + (t + 1) * G, nm0, nn0);
+        f32x4 bn[8];
+        if constexpr (LNF) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bn[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            load_bias(nn0, bn);
+        }
+        [[maybe_unused]] f32x4 gate4[8];
+        [[maybe_unused]] unsigned keepbits = 0xffu;
+        if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                gate4[i] = p.gate ? *reinterpret_cast<const f32x4*>(p.gate + n0 + wn * 128 + i * 16 + 4 * fq) : f32x4{1.f, 1.f, 1.f, 1.f};
+            if (p.rowmask && p.rowbits) keepbits = (unsigned)p.rowbits[((m0 + wm * 128) >> 7) * 16 + fr];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(gate4[i]));
+            asm volatile("" ::"v"(keepbits));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(bn[i]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and the stages requested ahead (and this tile's fold operands) have landed
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (EPI == EPI_RESID) {
+            resid_half(X0{}, gate4, keepbits);
+            resid_half(X1{}, gate4, keepbits);
+        } else {
+            if (p.act == ACT_GELU_TANH) {
+                store_half(X0{}, std::integral_constant<int, ACT_GELU_TANH>{});
+                store_half(X1{}, std::integral_constant<int, ACT_GELU_TANH>{});
+            } else {
+                store_half(X0{}, std::integral_constant<int, ACT_NONE>{});
+                store_half(X1{}, std::integral_constant<int, ACT_NONE>{});
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc_from(bn);
+        m0 = nm0;
+        n0 = nn0;
+        if constexpr (LNF) {
+            if (!last) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the epilogue's reads of the staging area are done before it is rewritten)
+                stage_lnf();
+            }
+        }
+    }
+#undef W4_ACC
+#undef W4_DSR
+}
+}  // namespace
+
+int g_gemm_w4 = 1;  // tuning knob ("gemm_w4"): 1 = whole-tile block linears with at least one 256 x 256 tile per CU run on the one-wave-per-SIMD kernel
+
+int gemm_persist_grid();  // gemm_fast.hip
+
+bool gemm_w4_ok(const GemmParams& p, int mode, int epi) {
+    if (!g_gemm_w4 || mode != GEMM_DENSE) return false;
+    if (p.M % 256 != 0 || p.N % 256 != 0 || p.K % 128 != 0 || p.K < 256 || (p.lda & 7) || (p.ldw & 7) || p.a_row_mod != 0 || p.row0 != 0) return false;
+    if ((p.M / 256) * (p.N / 256) < gemm_persist_grid()) return false;  // small launches: the 8-wave kernel's narrower tiles
+    if ((size_t)255 * (size_t)(p.lda > p.ldw ? p.lda : p.ldw) * 2 + 128 > 0x7fffffffull) return false;
+    if (p.lnf_partial || p.fin_counter || p.pf_n[0] || p.pf_n[1]) return false;
+    const bool lnf = p.lnf_stats != nullptr;
+    if (epi == EPI_STORE_T || epi == EPI_ROPE_T) {
+        if (!p.out_t || (p.ldo & 7) || !(p.act == ACT_NONE || p.act == ACT_GELU_TANH)) return false;
+        if (lnf ? (!p.lnf_c1 || !p.lnf_c2) : !p.bias) return false;
+        if (epi == EPI_ROPE_T && (p.rows_per_batch < 128 || !p.rope || p.rope_inner % 64 != 0)) return false;
+        return true;
+    }
+    if (epi == EPI_RESID) {
+        if (lnf || !p.add2_f16 || !p.out_f || (p.ldof & 7) || p.act != ACT_NONE || !p.bias) return false;
+        if ((p.gate && p.gate_bstride != 0) || (p.rowmask && !p.rowbits)) return false;
+        if (p.stats_out && (p.N % 64 != 0 || p.stats_ld < p.M)) return false;
+        return true;
+    }
+    return false;
+}
+
+int launch_gemm_w4(const GemmParams& p, int epi, hipStream_t stream) {
+    const int tiles_n = p.N / 256, nblocks = (p.M / 256) * tiles_n;
+    const int pg = gemm_persist_grid();
+    const dim3 grid(nblocks < pg ? nblocks : pg), block(256);
+    const bool lnf = p.lnf_stats != nullptr;
+    if (epi == EPI_STORE_T && lnf)
+        hipLaunchKernelGGL((gemm_w4_kernel<EPI_STORE_T, true>), grid, block, 0, stream, p, tiles_n, nblocks);
+    else if (epi == EPI_STORE_T)
+        hipLaunchKernelGGL((gemm_w4_kernel<EPI_STORE_T, false>), grid, block, 0, stream, p, tiles_n, nblocks);
+    else if (epi == EPI_ROPE_T && lnf)
+        hipLaunchKernelGGL((gemm_w4_kernel<EPI_ROPE_T, true>), grid, block, 0, stream, p, tiles_n, nblocks);
+    else if (epi == EPI_ROPE_T)
+        hipLaunchKernelGGL((gemm_w4_kernel<EPI_ROPE_T, false>), grid, block, 0, stream, p, tiles_n, nblocks);
+    else if (epi == EPI_RESID)
+        hipLaunchKernelGGL((gemm_w4_kernel<EPI_RESID, false>), grid, block, 0, stream, p, tiles_n, nblocks);
+    else
+        return f5_fail(F5_EINVAL, "gemm_w4: unsupported epilogue %d", epi);
+    F5_LAUNCH_CHECK();
+    return 0;
+}

@@ -514,3 +514,81 @@ def test_layernorm_fold_site_against_fp64(M, D, N, Kb, epi, offset):
     err = rel_l2(out, ref)
     print(f"ln_fold M={M} D={D} N={N} epi={epi} offset={offset}: rel-L2 {err:.2e}")
     assert err < 3e-3  # bf16 output rounding (2^-9 relative per element) + fp16 rounding of W'
+
+
+def _with_knob(lib, key, value, fn):
+    from eraxvif5tts_amd import _lib
+    _lib.check(lib.f5_tuning_set(key, value))
+    try:
+        return fn()
+    finally:
+        _lib.check(lib.f5_tuning_set(key, 1))
+
+
+@pytest.mark.parametrize("epi_name,shape,seq", [("store", (8192, 2048, 256), 0), ("store", (8192, 2048, 1024), 0), ("rope", (8192, 3072, 384), 1024),
+                                                ("rope", (16384, 1536, 1024), 2048), ("resid", (16384, 1024, 512), 0), ("resid_masked", (16384, 1024, 2048), 0)])
+def test_w4_kernel_equals_the_8_wave_kernel(epi_name, shape, seq):
+    """Round 4, late: whole-tile block linears with at least one 256 x 256 tile per CU run on the one-wave-per-SIMD kernel (csrc/gemm_w4.hip: four
+    waves, 128 x 128 outputs per wave, 64-deep stages refilled in place, hand-placed main loop).  Same MFMA, K order, start value and epilogue
+    arithmetic as the 8-wave persistent kernel, so the outputs must agree BIT FOR BIT (knob gemm_w4 = 0 selects the 8-wave kernel) -- store + GELU,
+    QKV + RoPE (first head / all heads), the in-place fp16 residual update with and without a row mask -- and both agree with fp64."""
+    import gpu_helpers as G
+    from eraxvif5tts_amd import _lib
+    lib = _lib.load()
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + 7 * N + K)
+    A, W, b = G.bf16_round(torch.randn(M, K, generator=g)), G.bf16_round(torch.randn(N, K, generator=g) / math.sqrt(K)), torch.randn(N, generator=g)
+    if epi_name.startswith("resid"):
+        gate = torch.randn(N, generator=g)
+        rowmask = (torch.rand(M, generator=g) > 0.2) if epi_name == "resid_masked" else None
+        x = (torch.randn(M, N, generator=g) * 3).half().float()
+        run = lambda: G.op_linear_fused(1, G.EPI_RESID, A, W, b, "none", gate, rowmask, stream_in=x)
+        upd = gate.double() * (A.double() @ W.double().t() + b.double())
+        if rowmask is not None:
+            upd = upd * rowmask[:, None].double()
+        ref, tol = (x.double() + upd).float(), 6e-4
+    else:
+        epi = {"store": G.EPI_STORE_T, "rope": G.EPI_ROPE_T}[epi_name]
+        act = "gelu_tanh" if epi_name == "store" else "none"
+        rope, heads = None, 0
+        if epi_name == "rope":
+            ang = torch.rand(seq, 32, generator=g) * 6.28
+            rope, heads = torch.stack([ang.cos(), ang.sin()], dim=-1), (1 if N == 3072 else N // 3 // 64)
+        run = lambda: G.op_linear_fused(1, epi, A, W, b, act, None, None, rope, heads, seq)
+        ref, tol = _fused_ref(epi, A, W, b, act, None, None, rope, heads, seq), 3e-3
+    new = run()
+    old = _with_knob(lib, b"gemm_w4", 0, run)
+    assert rel_l2(new, ref) < tol and rel_l2(old, ref) < tol
+    assert torch.equal(new, old)
+
+
+@pytest.mark.parametrize("N,Kb,epi", [(3072, 1024, 4), (2048, 2048, 0), (3072, 1024, -16)])
+def test_w4_kernel_layernorm_fold_site_equals_the_8_wave_kernel(N, Kb, epi):
+    """The LayerNorm fold of one call site at a size the one-wave-per-SIMD kernel takes (M = 16 384 token rows: producer 64 x 4, consumer 64 x 8 / 12
+    tiles): in-place residual epilogue with partial row statistics -> statistics -> fp16-operand projection with the fold epilogue (+ RoPE / GELU).
+    Stream, statistics and output bit for bit against the 8-wave kernel (gemm_w4 = 0)."""
+    import gpu_helpers as G
+    from eraxvif5tts_amd import _lib
+    lib = _lib.load()
+    M, D = 16384, 1024
+    rope_heads = 1
+    if epi < 0:
+        rope_heads, epi = -epi, 4
+    g = torch.Generator().manual_seed(N + Kb + epi)
+    x = torch.randn(M, D, generator=g) * 1.7 + torch.randn(M, 1, generator=g) * 0.5
+    A = G.bf16_round(torch.randn(M, Kb, generator=g))
+    Wo = G.bf16_round(torch.randn(D, Kb, generator=g) / Kb ** 0.5)
+    bo, gate = torch.randn(D, generator=g) * 0.1, torch.randn(D, generator=g) * 0.3
+    W, bias = torch.randn(N, D, generator=g) / D ** 0.5, torch.randn(N, generator=g) * 0.1
+    scale, shift = torch.randn(D, generator=g) * 0.2, torch.randn(D, generator=g) * 0.3
+    seq = 2048
+    rope = None
+    if epi == 4:
+        ang = torch.arange(seq)[:, None] * (1.0 / 10000.0 ** (torch.arange(0, 64, 2) / 64.0))[None, :]
+        rope = torch.stack([ang.cos(), ang.sin()], dim=-1).reshape(seq, 64).float()
+    run = lambda: G.op_ln_fold(epi, x, A, Wo, bo, gate, W, bias, scale, shift, pivot=None, act="gelu_tanh" if epi == 0 else "none", rope=rope,
+                               rope_heads=rope_heads, seq=seq)
+    new = run()
+    old = _with_knob(lib, b"gemm_w4", 0, run)
+    for a, c in zip(new, old):
+        assert torch.isfinite(a).all() and torch.equal(a, c)

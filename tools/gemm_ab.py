@@ -11,7 +11,7 @@ lib = _lib.load()
 _lib.require_gpu()
 rows = int(sys.argv[1])
 configs = sys.argv[2:] or ["base"]
-DEFAULTS = {"gemm_variant": 1, "gemm_persist": 1, "gemm_lean": 1, "gemm_group": 0, "gemm_tile": 0, "gemm_bm128": 1}
+DEFAULTS = {"gemm_variant": 1, "gemm_persist": 1, "gemm_lean": 1, "gemm_group": 0, "gemm_tile": 0, "gemm_bm128": 1, "gemm_w4": 1}
 
 
 def apply(cfg):

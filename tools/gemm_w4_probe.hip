@@ -129,33 +129,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto body = [&](auto xc, auto issuec, auto waitc) {
         constexpr int X = decltype(xc)::value;
         constexpr bool ISSUE = decltype(issuec)::value, WAITV = decltype(waitc)::value;
+        // schedule: RD1 = the 16 fragment reads of sub-step 1 at MFMA slots R1S * k; B1 (lgkmcnt(0) + barrier) behind slot B1P; the 16 DMA requests at
+        // slots D0 + DS * k; B2 (counted vmcnt + barrier) behind slot B2P; RD0 = the next iteration's first fragments at slots R0 + R0S * k
+        // SCHED >= 10: timing-only ablations of schedule 1 (wrong results): 10 no DMA requests, 11 no fragment reads, 12 neither, 13 neither and no
+        // barriers / waits (MFMA stream alone), 14 everything but the barriers
+        // 17: MFMA stream alone, epilogue without its stores; 18: MFMA stream alone, half of the workgroups start half a tile late; 19: schedule 1
+        // with that start skew; 20: schedule 1 without the stores
+        constexpr bool NO_DMA = SCHED == 10 || SCHED == 12 || SCHED == 13 || SCHED == 17 || SCHED == 18, NO_RD = SCHED == 11 || NO_DMA && SCHED != 10, NO_BAR = SCHED == 13 || SCHED == 14 || SCHED == 17 || SCHED == 18;
+        constexpr int R1S = SCHED == 0 ? 3 : 2, B1P = SCHED == 0 ? 49 : 40, D0 = SCHED == 0 ? 50 : 42, DS = (SCHED == 2 || SCHED == 4) ? 2 : 3;
+        constexpr int B2P = SCHED == 0 ? 100 : (SCHED == 3 || SCHED == 4 ? 78 : 86), R0 = B2P + 2, R0S = SCHED == 0 ? 0 : 2;
         static_for<128>([&](auto nc) {
             (void)acc; (void)fw; (void)fa;
             constexpr int n = decltype(nc)::value;
             constexpr int s = n / 64, i = (n % 64) / 8, j = n % 8;
             asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fw[s][i]), "v"(fa[s][j]));
-            if constexpr (n < 48 && n % 3 == 0) rd(std::integral_constant<int, 1>{}, xc, std::integral_constant<int, n / 3>{});
-            if constexpr (n == 49) {  // B1: every wave is done with buffer X
+            if constexpr (!NO_RD && n < 16 * R1S && n % R1S == 0) rd(std::integral_constant<int, 1>{}, xc, std::integral_constant<int, n / R1S>{});
+            if constexpr (n == B1P && !NO_BAR) {  // B1: every wave is done with buffer X
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
-            if constexpr (ISSUE && n >= 50 && n < 98 && (n - 50) % 3 == 0) {
-                constexpr int pc = (n - 50) / 3;
+            if constexpr (ISSUE && !NO_DMA && n >= D0 && n < D0 + 16 * DS && (n - D0) % DS == 0) {
+                constexpr int pc = (n - D0) / DS;
                 if constexpr (pc < 8)
                     dma(X * OPB + wdst + pc * 1024, voffA[pc], baseA);
                 else
                     dma(2 * OPB + X * OPB + wdst + (pc - 8) * 1024, voffW[pc - 8], baseW);
             }
-            if constexpr (n == 100) {  // B2: the other buffer (next iteration's stage) has landed for everyone
-                if constexpr (WAITV && ISSUE)
-                    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-                else if constexpr (WAITV)
-                    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if constexpr (n == B2P && !NO_BAR) {  // B2: the other buffer (next iteration's stage) has landed for everyone
+                constexpr int issued = (!ISSUE || NO_DMA) ? 0 : (B2P < D0 ? 0 : ((B2P - D0) / DS + 1 > 16 ? 16 : (B2P - D0) / DS + 1));  // this iteration's requests so far
+                if constexpr (WAITV)
+                    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(issued) : "memory");
                 else
                     asm volatile("s_barrier" ::: "memory");
             }
-            if constexpr (n >= 102 && n < 126) {
-                constexpr int a = n - 102;  // 24 slots, 16 reads: slots 0,1,3,4,6,7,...
-                if constexpr (a % 3 != 2) rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 1 - X>{}, std::integral_constant<int, a - a / 3>{});
+            if constexpr (R0S == 0) {
+                if constexpr (n >= 102 && n < 126) {
+                    constexpr int a = n - 102;  // 24 slots, 16 reads: slots 0,1,3,4,6,7,...
+                    if constexpr (a % 3 != 2) rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 1 - X>{}, std::integral_constant<int, a - a / 3>{});
+                }
+            } else {
+                if constexpr (!NO_RD && n >= R0 && n < R0 + 16 * R0S && (n - R0) % R0S == 0)
+                    rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 1 - X>{}, std::integral_constant<int, (n - R0) / R0S>{});
             }
             if constexpr (n == 127) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         });
@@ -169,6 +182,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int pc = 0; pc < 8; ++pc) dma(2 * OPB + X * OPB + wdst + pc * 1024, voffW[pc], baseW);
     };
+    if constexpr (SCHED == 18 || SCHED == 19) {
+        if ((blockIdx.x >> 3) & 1)
+            for (int i = 0; i < K / 340; ++i) __builtin_amdgcn_s_sleep(127);  // 64 x 127 cycles each: about half a tile at K = 1024
+    }
     issue_all(0);
     front_advance();
     issue_all(1);
@@ -193,7 +210,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 asm volatile("" : "+a"(acc[i][j]));
                 asm volatile("" : "+a"(acc[i + 1][j]));
                 const u32x4 q = pair_swap(to_bf16x4(acc[i][j]), to_bf16x4(acc[i + 1][j]));
-                *reinterpret_cast<u32x4*>(orow + (size_t)16 * j * ldc + 32 * (i / 2)) = q;
+                if constexpr (SCHED == 17 || SCHED == 20)
+                    asm volatile("" ::"v"(q));
+                else if constexpr (SCHED == 22 || SCHED == 23)  // non-temporal stores (what the vendor kernel uses)
+                    __builtin_nontemporal_store(q, reinterpret_cast<u32x4*>(orow + (size_t)16 * j * ldc + 32 * (i / 2)));
+                else
+                    *reinterpret_cast<u32x4*>(orow + (size_t)16 * j * ldc + 32 * (i / 2)) = q;
             });
         });
     };
@@ -208,7 +230,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             body(X0{}, T{}, T{});  // (the very first iteration waits: stage 1 was requested just now)
         else
             body(X0{}, T{}, F{});
-        body(X1{}, T{}, T{});
+        if constexpr (SCHED == 21 || SCHED == 23) {  // 21 / 23: timing only, no wait in a tile's second iteration either
+            if (t == 0) body(X1{}, T{}, T{}); else body(X1{}, T{}, F{});
+        } else {
+            body(X1{}, T{}, T{});
+        }
         const int kend = last ? nk - 2 : nk;
         for (int kt = 2; kt < kend; kt += 2) {
             body(X0{}, T{}, T{});
@@ -240,13 +266,19 @@ __global__ void ref_rows(const bf16_t* A, const bf16_t* W, float* out, const int
 static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
 static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
 
+static void launch(int sched, dim3 grid, const bf16_t* dA, const bf16_t* dW, bf16_t* dC, int M, int N, int K, int tiles_n, int nblocks) {
+#define W4_CASE(S) case S: hipLaunchKernelGGL(w4_kernel<S>, grid, dim3(256), 0, 0, dA, dW, dC, M, N, K, K, K, N, tiles_n, nblocks, 8); break;
+    switch (sched) { W4_CASE(0) W4_CASE(1) W4_CASE(3) W4_CASE(10) W4_CASE(11) W4_CASE(12) W4_CASE(13) W4_CASE(14) W4_CASE(17) W4_CASE(18) W4_CASE(19) W4_CASE(20) W4_CASE(21) W4_CASE(22) W4_CASE(23) }
+}
+
 int main(int argc, char** argv) {
     struct Shape { const char* name; int M, N, K; };
-    const Shape shapes[] = {{"small", 1024, 512, 512}, {"qkv", 65536, 3072, 1024}, {"ff1", 65536, 2048, 1024}, {"ff2", 65536, 1024, 2048}, {"out", 65536, 1024, 1024}};
+    const Shape shapes[] = {{"small", 1024, 512, 512}, {"qkv", 65536, 3072, 1024}, {"ff1", 65536, 2048, 1024}, {"ff2", 65536, 1024, 2048}, {"out", 65536, 1024, 1024}, {"cube", 8192, 8192, 8192}};
     int ncu = 256;
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     ncu = prop.multiProcessorCount & ~7;
+    for (int sched : {1, 21, 22, 23, 1, 22})
     for (const Shape& sh : shapes) {
         const int M = sh.M, N = sh.N, K = sh.K;
         std::vector<uint16_t> hA((size_t)M * K), hW((size_t)N * K);
@@ -263,7 +295,7 @@ int main(int argc, char** argv) {
         CK(hipMemset(dC, 0xff, (size_t)M * N * 2));
         const int tiles_m = M / 256, tiles_n = N / 256, nblocks = tiles_m * tiles_n;
         const int grid = nblocks < ncu ? nblocks : ncu;
-        hipLaunchKernelGGL(w4_kernel<0>, dim3(grid), dim3(256), 0, 0, dA, dW, dC, M, N, K, K, K, N, tiles_n, nblocks, 8);
+        launch(sched, dim3(grid), dA, dW, dC, M, N, K, tiles_n, nblocks);
         CK(hipGetLastError());
         CK(hipDeviceSynchronize());
         // check sampled rows
@@ -295,15 +327,14 @@ int main(int argc, char** argv) {
         float best = 1e9f;
         for (int rnd2 = 0; rnd2 < 3; ++rnd2) {
             CK(hipEventRecord(e0));
-            for (int it = 0; it < 10; ++it)
-                hipLaunchKernelGGL(w4_kernel<0>, dim3(grid), dim3(256), 0, 0, dA, dW, dC, M, N, K, K, K, N, tiles_n, nblocks, 8);
+            for (int it = 0; it < 10; ++it) launch(sched, dim3(grid), dA, dW, dC, M, N, K, tiles_n, nblocks);
             CK(hipEventRecord(e1));
             CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (ms / 10 < best) best = ms / 10;
         }
-        printf("%s M=%d N=%d K=%d: %.1f us = %.0f TF | max abs err %.4g (max |ref| %.3g)%s\n", sh.name, M, N, K, best * 1e3, 2.0 * M * N * K / best / 1e9, maxerr, maxref,
-               maxerr <= 0.02 * maxref + 1e-3 ? "" : "  <-- MISMATCH");
+        printf("[sched %d] %s M=%d N=%d K=%d: %.1f us = %.0f TF | max abs err %.4g (max |ref| %.3g)%s\n", sched, sh.name, M, N, K, best * 1e3, 2.0 * M * N * K / best / 1e9, maxerr, maxref,
+               (sched >= 10 && sched != 22) ? "  (timing only)" : (maxerr <= 0.02 * maxref + 1e-3 ? "" : "  <-- MISMATCH"));
         fflush(stdout);
         (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dC); (void)hipFree(dRows); (void)hipFree(dRef);
     }
