@@ -30,13 +30,14 @@ typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 
 namespace {
 constexpr int OPB = 32768;          // one operand of one stage: 256 rows x 128 bytes
-constexpr int EPI_LDS = 4 * OPB;    // epilogue operands of the LayerNorm fold: 4 waves x 2 KiB behind the stage buffers
+constexpr int EPI_LDS = 4 * OPB;    // behind the stage buffers: the LayerNorm fold's epilogue operands (4 waves x 2 KiB), or bias[N] | gate[N] of an in-place residual launch
+constexpr int EPI_LDS_BYTES = 16384;
 
 template <int EPI, bool LNF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_w4_kernel(GemmParams p, int tiles_n, int nblocks) {
     static_assert(EPI == EPI_STORE_T || EPI == EPI_ROPE_T || EPI == EPI_RESID, "block linears only");
     static_assert(!LNF || EPI != EPI_RESID, "LayerNorm fold: QKV (+ RoPE) and FF1 (+ GELU)");
-    __shared__ __attribute__((aligned(1024))) char smem[4 * OPB + 4 * 2048];
+    __shared__ __attribute__((aligned(1024))) char smem[4 * OPB + EPI_LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -94,7 +95,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (++f_k == nk) {
             f_k = 0;
             f_tile += G;
-            if (f_tile < nblocks) front_tile();
+            if (f_tile < nblocks) {
+                front_tile();
+            } else {  // past the last tile: walk its stages again (valid addresses; the requests are never read)
+                f_tile -= G;
+                baseA -= (size_t)nk * 128;
+                baseW -= (size_t)nk * 128;
+            }
         }
     };
     // ---- fragment read addresses (LDS byte addresses; the 16-row tile index and the buffer are immediate offsets).  Layout: [A buffer 0][A buffer 1]
@@ -120,11 +127,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // 40: lgkmcnt(0) + barrier = every wave is done with buffer X; the 16 DMA requests of the stage two iterations ahead into buffer X (slots 42, 45,
     // .. 87); B2 behind slot 86: counted vmcnt (this iteration's 15 requests so far may fly, everything older has landed) + barrier = the other
     // buffer is complete; RD0: the next iteration's sub-step-0 fragments from it (slots 88, 90, .. 118); lgkmcnt(0) behind the last MFMA.
-    // ISSUE false: the last two iterations of the last tile request nothing.  WAITV false: a tile's first iteration after an epilogue (everything
+    // The main loop exists in few copies with straight-line control flow between them (a conditional INSIDE the iteration loop made the register
+    // allocator shuffle and spill the 256 tied AccVGPR operands).  So nothing about an iteration is conditional: the last two iterations of the last tile
+    // request the last tile's stages again (never read; the final vmcnt(0) in front of the epilogue retires them before the wave ends), and a
+    // tile's last iteration reads the next tile's first fragments although the epilogue reads them AGAIN behind itself -- which is what frees
+    // their 64 registers inside the epilogue: the values read here are dead there.  WAITV false: a tile's first iteration after an epilogue (everything
     // requested before the epilogue was waited for in front of it; a wait here would also wait for the epilogue's stores: they share vmcnt).
-    auto body = [&](auto xc, auto issuec, auto waitc) {
+    auto body = [&](auto xc, auto waitc) {
         constexpr int X = decltype(xc)::value;
-        constexpr bool ISSUE = decltype(issuec)::value, WAITV = decltype(waitc)::value;
+        constexpr bool WAITV = decltype(waitc)::value;
         constexpr int R1S = 2, B1P = 40, D0 = 42, DS = 3, B2P = 86, R0 = 88, R0S = 2;
         static_for<128>([&](auto nc) {
             (void)acc; (void)fw; (void)fa; (void)voffA; (void)voffW; (void)baseA; (void)baseW;
@@ -136,7 +147,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fw[s][i]), "v"(fa[s][j]));
             if constexpr (n < 16 * R1S && n % R1S == 0) rd(std::integral_constant<int, 1>{}, xc, std::integral_constant<int, n / R1S>{});
             if constexpr (n == B1P) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if constexpr (ISSUE && n >= D0 && n < D0 + 16 * DS && (n - D0) % DS == 0) {
+            if constexpr (n >= D0 && n < D0 + 16 * DS && (n - D0) % DS == 0) {
                 constexpr int pc = (n - D0) / DS;
                 if constexpr (pc < 8)
                     dma16w(X * OPB + wdst + pc * 1024, voffA[pc], baseA);
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     dma16w(2 * OPB + X * OPB + wdst + (pc - 8) * 1024, voffW[pc - 8], baseW);
             }
             if constexpr (n == B2P) {
-                constexpr int issued = !ISSUE ? 0 : (B2P - D0) / DS + 1;  // this iteration's requests so far
+                constexpr int issued = (B2P - D0) / DS + 1;  // this iteration's requests so far
                 if constexpr (WAITV)
                     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(issued) : "memory");
                 else
@@ -154,9 +165,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 1 - X>{}, std::integral_constant<int, (n - R0) / R0S>{});
             if constexpr (n == 127) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         });
-        if constexpr (ISSUE) front_advance();
+        front_advance();
     };
 
+    using T = std::true_type;
+    using F = std::false_type;
+    using X0 = std::integral_constant<int, 0>;
+    using X1 = std::integral_constant<int, 1>;
     // ---- per-tile epilogue operands
     int m0, n0;
     tile_mn(blockIdx.x, m0, n0);
@@ -236,11 +251,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             *reinterpret_cast<u32x4*>(o + 32) = q1;
         });
     };
-    // ---- in-place update of the fp16 residual stream by one 64-feature half (= lean_resid_f16 of gemm_fast.hip for one of its waves), with the
-    // LayerNorm fold's partial row statistics of the values just stored
-    [[maybe_unused]] auto emit_stats = [&](int nb, int m, float pivot, const f32x4& h0, const f32x4& h1, const f32x4& h2, const f32x4& h3) {
-        const f32x4 pv{pivot, pivot, pivot, pivot};
-        const f32x4 d0 = h0 - pv, d1 = h1 - pv, d2 = h2 - pv, d3 = h3 - pv;
+    // ---- in-place update of the fp16 residual stream (= lean_resid_f16 of gemm_fast.hip for two of its waves), with the LayerNorm fold's partial
+    // row statistics of the values just stored.  bias[N] and gate[N] of the launch live in LDS (staged once at kernel start), not in registers, and
+    // the next tile's first fragments are read behind the epilogue: the registers go to the stream tile's loads in flight.
+    [[maybe_unused]] const float* const lds_bias = reinterpret_cast<const float*>(smem + EPI_LDS);
+    [[maybe_unused]] const float* const lds_gate = lds_bias + p.N;
+    [[maybe_unused]] auto emit_stats = [&](int nb, int m /* row inside the wave's 128 */, float pivot, const f32x4& h0, const f32x4& h1, const f32x4& h2, const f32x4& h3) {
+        const f32x4 npv{-pivot, -pivot, -pivot, -pivot};  // (h + (-pivot) == h - pivot bit for bit; the add form packs into v_pk_add_f32)
+        const f32x4 d0 = h0 + npv, d1 = h1 + npv, d2 = h2 + npv, d3 = h3 + npv;
         const f32x4 a = (d0 + d1) + (d2 + d3);
         const f32x4 q = __builtin_elementwise_fma(d3, d3, __builtin_elementwise_fma(d2, d2, __builtin_elementwise_fma(d1, d1, d0 * d0)));
         const float s1 = (a[0] + a[1]) + (a[2] + a[3]), s2 = (q[0] + q[1]) + (q[2] + q[3]);
@@ -249,78 +267,108 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         float t = a0 + b0, z = 0.0f;
         asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(t), "+v"(z));
         const float tot = t + z;
-        if (fq < 2) p.stats_out[((size_t)(nb >> 6) * p.stats_ld + m) * 2 + fq] = tot;
+        if (fq < 2) {
+            char* sb = reinterpret_cast<char*>(p.stats_out + ((size_t)(nb >> 6) * p.stats_ld + (m0 + wm * 128)) * 2);  // (scalar base + 32-bit lane offset)
+            *reinterpret_cast<float*>(sb + (unsigned)((m * 2 + fq) * 4)) = tot;
+        }
     };
-    [[maybe_unused]] auto resid_half = [&](auto hc, const f32x4 (&gate4)[8], unsigned keepbits) {
-        constexpr int h = decltype(hc)::value;
-        const int nb = n0 + wn * 128 + h * 64;
-        const size_t row0 = (size_t)(m0 + wm * 128 + fr);
-        _Float16* hrow = reinterpret_cast<_Float16*>(p.out_f) + row0 * p.ldof + nb + 16 * (fq & 1) + 8 * (fq >> 1);
-        u32x4 adA[2], adB[2];
-        auto load_x = [&](auto jc, u32x4 (&dst)[2]) __attribute__((always_inline)) {
-            constexpr int j = decltype(jc)::value;
-            dst[0] = *reinterpret_cast<const u32x4*>(hrow + (size_t)16 * j * p.ldof);
-            dst[1] = *reinterpret_cast<const u32x4*>(hrow + (size_t)16 * j * p.ldof + 32);
+    [[maybe_unused]] auto resid_tile = [&]() {
+        // (the lane's row index through an opaque asm: otherwise every per-lane address of the epilogue is hoisted out of the tile loop as a
+        //  64-bit loop invariant and spilled across the main loop, where the registers are the fragments')
+        int fr = lane & 15, fq = lane >> 4;
+        asm volatile("" : "+v"(fr), "+v"(fq));
+        // (one scalar base + eight 32-bit lane offsets, one per token tile; halves and feature-tile pairs are immediates: 64-bit addresses per
+        //  access would cost 64 registers here)
+        char* const sbase = reinterpret_cast<char*>(p.out_f) + ((size_t)(m0 + wm * 128) * p.ldof + n0 + wn * 128) * 2;
+        unsigned offj[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) offj[j] = (unsigned)(((fr + 16 * j) * p.ldof + 16 * (fq & 1) + 8 * (fq >> 1)) * 2);
+        unsigned keepbits = 0xffu;
+        if (p.rowmask && p.rowbits) keepbits = (unsigned)p.rowbits[((m0 + wm * 128) >> 7) * 16 + fr];
+        float piv[8];
+        if (p.stats_out) {
+            const float* pbase = p.stats_pivot ? p.stats_pivot + (size_t)(m0 + wm * 128) * 2 : nullptr;  // (scalar base + 32-bit lane offset)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) piv[j] = pbase ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pbase) + (unsigned)((fr + 16 * j) * 8)) : 0.0f;
+        }
+        // A lone wave cannot hide a load behind another wave's work: the stream tile is requested AHEAD (half, token tile) steps = 2 AHEAD loads
+        // ahead of its use -- the first AHEAD before the first store, the others one by one behind a step's stores (a load issued behind a store also
+        // waits for that store, vmcnt retires in order; AHEAD steps later the store is long acknowledged).  More than 6 spills accumulators.
+        u32x4 xs[2][8][2];  // [half][token tile][feature-tile pair]: the stream tile as stored (8 fp16 per lane and entry)
+        auto load_step = [&](auto sc) __attribute__((always_inline)) {
+            constexpr int h = decltype(sc)::value / 8, j = decltype(sc)::value % 8;
+            xs[h][j][0] = *reinterpret_cast<const u32x4*>(sbase + offj[j] + h * 128);
+            xs[h][j][1] = *reinterpret_cast<const u32x4*>(sbase + offj[j] + h * 128 + 64);
         };
+        constexpr int AHEAD = 4;
+        static_for<AHEAD>([&](auto sc) { load_step(sc); });
+        __builtin_amdgcn_sched_barrier(0);
+        const bool all_kept = __builtin_amdgcn_ballot_w64(keepbits != 0xffu) == 0ull;  // wave-uniform: no masked row in this wave's 128 token rows
         auto widen_h = [](unsigned lo, unsigned hi) __attribute__((always_inline)) {
             const f16x4_t hv = __builtin_bit_cast(f16x4_t, u32x2{lo, hi});
             return f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
         };
-        auto to_h = [](const f32x4& v) __attribute__((always_inline)) {
+        auto to_h16 = [](const f32x4& v) __attribute__((always_inline)) {  // saturating fp16 store form
             f16x4_t hv;
 #pragma unroll
             for (int e = 0; e < 4; ++e) hv[e] = (_Float16)__builtin_amdgcn_fmed3f(v[e], -65504.0f, 65504.0f);
-            return __builtin_bit_cast(bf16x4, hv);
+            return hv;
         };
-        auto h_round4 = [](const f32x4& v) {
-            f32x4 r;
+        auto h_f32 = [](const f16x4_t& hv) __attribute__((always_inline)) { return f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]}; };
+        // partial row statistics: one scalar base per half, the row's 32-bit offset per token tile
+        auto steps = [&](auto keptc) __attribute__((always_inline)) {
+            constexpr bool ALL = decltype(keptc)::value;
+            static_for<16>([&](auto sc) __attribute__((always_inline)) {
+                constexpr int h = decltype(sc)::value / 8, j = decltype(sc)::value % 8;
+                const int nb = n0 + wn * 128 + h * 64;
+                f32x4 g4[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = (float)(_Float16)__builtin_amdgcn_fmed3f(v[e], -65504.0f, 65504.0f);
-            return r;
+                for (int ii = 0; ii < 4; ++ii) g4[ii] = *reinterpret_cast<const f32x4*>(lds_gate + nb + ii * 16 + 4 * fq);
+                f32x4 x0, x1, x2, x3;
+                {
+                    const u32x4 q = xs[h][j][0];  // inverse of pair_swap: this lane's 8 stored features -> the accumulator layout
+                    const u32x2 s0 = __builtin_amdgcn_permlane16_swap(q[0], q[2], false, false);
+                    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(q[1], q[3], false, false);
+                    x0 = widen_h(s0[0], s1[0]);
+                    x1 = widen_h(s0[1], s1[1]);
+                }
+                {
+                    const u32x4 q = xs[h][j][1];
+                    const u32x2 s0 = __builtin_amdgcn_permlane16_swap(q[0], q[2], false, false);
+                    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(q[1], q[3], false, false);
+                    x2 = widen_h(s0[0], s1[0]);
+                    x3 = widen_h(s0[1], s1[1]);
+                }
+                const f32x4 a0 = W4_ACC(h * 4 + 0, j), a1 = W4_ACC(h * 4 + 1, j), a2 = W4_ACC(h * 4 + 2, j), a3 = W4_ACC(h * 4 + 3, j);
+                f32x4 v0 = epi_axpy4(a0, g4[0], x0), v1 = epi_axpy4(a1, g4[1], x1), v2 = epi_axpy4(a2, g4[2], x2), v3 = epi_axpy4(a3, g4[3], x3);
+                if constexpr (!ALL) {  // masked query rows keep their value
+                    const bool keep = (keepbits >> j) & 1u;
+                    v0 = keep ? v0 : x0;
+                    v1 = keep ? v1 : x1;
+                    v2 = keep ? v2 : x2;
+                    v3 = keep ? v3 : x3;
+                }
+                const f16x4_t h0 = to_h16(v0), h1 = to_h16(v1), h2 = to_h16(v2), h3 = to_h16(v3);
+                *reinterpret_cast<u32x4*>(sbase + offj[j] + h * 128) = pair_swap(__builtin_bit_cast(bf16x4, h0), __builtin_bit_cast(bf16x4, h1));
+                *reinterpret_cast<u32x4*>(sbase + offj[j] + h * 128 + 64) = pair_swap(__builtin_bit_cast(bf16x4, h2), __builtin_bit_cast(bf16x4, h3));
+                if (p.stats_out) emit_stats(nb, fr + 16 * j, piv[j], h_f32(h0), h_f32(h1), h_f32(h2), h_f32(h3));
+                if constexpr (decltype(sc)::value + AHEAD < 16) load_step(std::integral_constant<int, decltype(sc)::value + AHEAD>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
         };
-        load_x(std::integral_constant<int, 0>{}, adA);
-        [[maybe_unused]] float piv[8];
-        if (p.stats_out) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) piv[j] = p.stats_pivot ? p.stats_pivot[(row0 + (size_t)16 * j) * 2] : 0.0f;
-        }
-        static_for<8>([&](auto jc) __attribute__((always_inline)) {
-            constexpr int j = decltype(jc)::value;
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (j + 1 < 8) {
-                if constexpr ((j + 1) & 1)
-                    load_x(std::integral_constant<int, j + 1>{}, adB);
-                else
-                    load_x(std::integral_constant<int, j + 1>{}, adA);
-            }
-            const bool keep = (keepbits >> j) & 1u;
-            f32x4 x0, x1, x2, x3;
-            {
-                const u32x4 q = (j & 1) ? adB[0] : adA[0];
-                const u32x2 s0 = __builtin_amdgcn_permlane16_swap(q[0], q[2], false, false);
-                const u32x2 s1 = __builtin_amdgcn_permlane16_swap(q[1], q[3], false, false);
-                x0 = widen_h(s0[0], s1[0]);
-                x1 = widen_h(s0[1], s1[1]);
-            }
-            {
-                const u32x4 q = (j & 1) ? adB[1] : adA[1];
-                const u32x2 s0 = __builtin_amdgcn_permlane16_swap(q[0], q[2], false, false);
-                const u32x2 s1 = __builtin_amdgcn_permlane16_swap(q[1], q[3], false, false);
-                x2 = widen_h(s0[0], s1[0]);
-                x3 = widen_h(s0[1], s1[1]);
-            }
-            const f32x4 a0 = W4_ACC(h * 4 + 0, j), a1 = W4_ACC(h * 4 + 1, j), a2 = W4_ACC(h * 4 + 2, j), a3 = W4_ACC(h * 4 + 3, j);
-            const f32x4 v0 = keep ? epi_axpy4(a0, gate4[h * 4 + 0], x0) : x0;
-            const f32x4 v1 = keep ? epi_axpy4(a1, gate4[h * 4 + 1], x1) : x1;
-            const f32x4 v2 = keep ? epi_axpy4(a2, gate4[h * 4 + 2], x2) : x2;
-            const f32x4 v3 = keep ? epi_axpy4(a3, gate4[h * 4 + 3], x3) : x3;
-            const size_t jo = (size_t)16 * j;
-            *reinterpret_cast<u32x4*>(hrow + jo * p.ldof) = pair_swap(to_h(v0), to_h(v1));
-            *reinterpret_cast<u32x4*>(hrow + jo * p.ldof + 32) = pair_swap(to_h(v2), to_h(v3));
-            if (p.stats_out) emit_stats(nb, (int)row0 + 16 * j, piv[j], h_round4(v0), h_round4(v1), h_round4(v2), h_round4(v3));
-        });
+        if (all_kept)
+            steps(std::true_type{});
+        else
+            steps(std::false_type{});
     };
 
+    if constexpr (EPI == EPI_RESID) {  // bias[N] | gate[N] of the launch into LDS (visible to every wave behind the prologue's barrier)
+        float* lb = reinterpret_cast<float*>(smem + EPI_LDS);
+        for (int i = tid; i < p.N; i += 256) {
+            lb[i] = p.bias[i];
+            lb[p.N + i] = p.gate ? p.gate[i] : 1.0f;
+        }
+    }
     // ---- prologue: stages 0 and 1 requested, stage 0 landed, first fragments read
     auto issue_all = [&](int X) {
 #pragma unroll
@@ -341,61 +389,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         load_bias(n0, bstart);
     }
     acc_from(bstart);
+    if constexpr (EPI == EPI_RESID) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this thread's part of the bias / gate image is written)
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LNF ? 21 : 16) : "memory");  // stage 0 has landed for everyone
     static_for<16>([&](auto ec) { rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, ec); });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-    using T = std::true_type;
-    using F = std::false_type;
-    using X0 = std::integral_constant<int, 0>;
-    using X1 = std::integral_constant<int, 1>;
     // a tile: nk iterations (nk even, >= 4), buffer = iteration & 1
     for (int t = 0; t < my_tiles; ++t) {
         const bool last = t + 1 == my_tiles;
         if (t == 0)
-            body(X0{}, T{}, T{});  // (the very first iteration waits: stage 1 was requested just now)
+            body(X0{}, T{});  // (the very first iteration waits: stage 1 was requested just now)
         else
-            body(X0{}, T{}, F{});
-        body(X1{}, T{}, T{});
-        const int kend = last ? nk - 2 : nk;
-        for (int kt = 2; kt < kend; kt += 2) {
-            body(X0{}, T{}, T{});
-            body(X1{}, T{}, T{});
+            body(X0{}, F{});  // a tile's first iteration behind an epilogue
+        body(X1{}, T{});
+        for (int kt = 2; kt < nk; kt += 2) {
+            body(X0{}, T{});
+            body(X1{}, T{});
         }
-        if (last) {
-            body(X0{}, F{}, T{});
-            body(X1{}, F{}, T{});
-        }
-        // the epilogue's per-tile operands and the NEXT tile's accumulator start are requested before the stores and waited for while only
-        // loads are in flight (loads and stores share vmcnt: a wait behind the stores would hold the wave until they are acknowledged)
         int nm0 = m0, nn0 = n0;
         if (!last) tile_mn(blockIdx.x + (t + 1) * G, nm0, nn0);
-        f32x4 bn[8];
-        if constexpr (LNF) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) bn[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        } else {
-            load_bias(nn0, bn);
-        }
-        [[maybe_unused]] f32x4 gate4[8];
-        [[maybe_unused]] unsigned keepbits = 0xffu;
         if constexpr (EPI == EPI_RESID) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stages requested ahead have landed: from here on only the epilogue's own traffic
+            __builtin_amdgcn_sched_barrier(0);
+            resid_tile();
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 bn[8];  // the next tile's accumulator start: its features' bias, from LDS
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                gate4[i] = p.gate ? *reinterpret_cast<const f32x4*>(p.gate + n0 + wn * 128 + i * 16 + 4 * fq) : f32x4{1.f, 1.f, 1.f, 1.f};
-            if (p.rowmask && p.rowbits) keepbits = (unsigned)p.rowbits[((m0 + wm * 128) >> 7) * 16 + fr];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(gate4[i]));
-            asm volatile("" ::"v"(keepbits));
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(bn[i]));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and the stages requested ahead (and this tile's fold operands) have landed
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (EPI == EPI_RESID) {
-            resid_half(X0{}, gate4, keepbits);
-            resid_half(X1{}, gate4, keepbits);
+            for (int i = 0; i < 8; ++i) bn[i] = *reinterpret_cast<const f32x4*>(lds_bias + nn0 + wn * 128 + i * 16 + 4 * fq);
+            acc_from(bn);
         } else {
+            // the NEXT tile's accumulator start is requested before the stores and waited for while only loads are in flight (loads and stores
+            // share vmcnt: a wait behind the stores would hold the wave until they are acknowledged)
+            f32x4 bn[8];
+            if constexpr (LNF) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bn[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                load_bias(nn0, bn);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(bn[i]));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and the stages requested ahead (and this tile's fold operands) have landed
+            __builtin_amdgcn_sched_barrier(0);
             if (p.act == ACT_GELU_TANH) {
                 store_half(X0{}, std::integral_constant<int, ACT_GELU_TANH>{});
                 store_half(X1{}, std::integral_constant<int, ACT_GELU_TANH>{});
@@ -403,16 +438,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 store_half(X0{}, std::integral_constant<int, ACT_NONE>{});
                 store_half(X1{}, std::integral_constant<int, ACT_NONE>{});
             }
+            __builtin_amdgcn_sched_barrier(0);
+            acc_from(bn);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        acc_from(bn);
         m0 = nm0;
         n0 = nn0;
-        if constexpr (LNF) {
-            if (!last) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the epilogue's reads of the staging area are done before it is rewritten)
-                stage_lnf();
-            }
+        if (!last) {
+            // the next tile's first fragments (its stage 0 sits in buffer 0: nk is even), and its fold operands
+            static_for<16>([&](auto ec) { rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, ec); });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (also: the epilogue's reads of the staging area are done before it is rewritten)
+            if constexpr (LNF) stage_lnf();
         }
     }
 #undef W4_ACC
@@ -441,6 +476,7 @@ bool gemm_w4_ok(const GemmParams& p, int mode, int epi) {
         if (lnf || !p.add2_f16 || !p.out_f || (p.ldof & 7) || p.act != ACT_NONE || !p.bias) return false;
         if ((p.gate && p.gate_bstride != 0) || (p.rowmask && !p.rowbits)) return false;
         if (p.stats_out && (p.N % 64 != 0 || p.stats_ld < p.M)) return false;
+        if ((size_t)p.N * 8 > (size_t)EPI_LDS_BYTES) return false;  // bias[N] | gate[N] live in LDS
         return true;
     }
     return false;
