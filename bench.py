@@ -237,8 +237,11 @@ def insitu_kernels(model, cfm, batch, B, N, nfe, args):
         a, n = C.c_float(0.0), C.c_int(0)
         _lib.check(lib.f5_plan_timing_site(plan, i, C.byref(a), C.byref(n)), "timing_site")
         return a.value, n.value
-    fold = C.c_int(0)
+    fold, w4 = C.c_int(0), C.c_int(0)
     _lib.check(lib.f5_plan_get_option(plan, b"ln_fold_active", C.byref(fold)), "plan_get_option")
+    _lib.check(lib.f5_plan_get_option(plan, b"gemm_w4", C.byref(w4)), "plan_get_option")
+    # (csrc/gemm_w4.hip, gemm_w4_ok: whole 256 x 256 tiles, at least one per CU -- the fused projection has 12 feature tiles per token tile)
+    insitu_kernels.w4 = bool(w4.value) and rows % 256 == 0 and (rows // 256) * 12 >= 256 and args.precision == "bf16"
     es = 2 if args.precision == "bf16" else 4
     xs = es  # storage bytes of a residual-stream element: fp16 in the bf16 production mode (blocks 1..21 of 22; the first reads fp32), fp32 otherwise
     work = {  # algorithmic work per launch: FLOP for the MFMA-bound kernels, bytes for the HBM-bound ones
@@ -624,10 +627,10 @@ def main():
         result["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
                               "traffic": traffic, "traffic_source": traffic_src,
-                              "kernel": ("gemm_fast_kernel<256,128,DENSE,QKV+RoPE epilogue,persistent grid,LayerNorm fold> (fp16 stream x per-time fp16 weights on "
-                                         "v_mfma_f32_16x16x32_f16; 21 of the 22 launches per evaluation, block 0's runs the bf16 build)"
-                                         if any("LayerNorm folded" in k["kernel"] for k in kernels) else
-                                         "gemm_fast_kernel<256,128,DENSE,QKV+RoPE epilogue,persistent grid>"),
+                              "kernel": (("gemm_w4_kernel<QKV+RoPE epilogue" if getattr(insitu_kernels, "w4", False) else "gemm_fast_kernel<256,128,DENSE,QKV+RoPE epilogue") +
+                                         (",persistent grid,LayerNorm fold> (fp16 stream x per-time fp16 weights on v_mfma_f32_16x16x32_f16; 21 of the 22 launches per "
+                                          "evaluation, block 0's runs the bf16 build)" if any("LayerNorm folded" in k["kernel"] for k in kernels) else ",persistent grid>") +
+                                         (" [one wave per SIMD: 4 waves x 128x128, 256x256x64 stages, csrc/gemm_w4.hip]" if getattr(insitu_kernels, "w4", False) else "")),
                               "launch": f"M={rows} N=3072 K=1024, {flops_qkv / 1e9:.1f} GFLOP, {ms_qkv:.4f} ms mean over {n_qkv} launches inside an "
                                         f"eager sample() (HIP event pairs on the launch stream)",
                               "kernels": kernels}

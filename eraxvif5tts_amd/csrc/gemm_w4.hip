@@ -123,10 +123,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if constexpr (S == 0) W4_DSR(fa[0][e - 8], ra0, X * OPB + (e - 8) * 2048); else W4_DSR(fa[1][e - 8], ra1, X * OPB + (e - 8) * 2048);
         }
     };
-    // One 64-deep iteration on buffer X: 128 MFMAs, and between them -- RD1: the 16 fragment reads of sub-step 1 (slots 0, 2, .. 30); B1 behind slot
-    // 40: lgkmcnt(0) + barrier = every wave is done with buffer X; the 16 DMA requests of the stage two iterations ahead into buffer X (slots 42, 45,
-    // .. 87); B2 behind slot 86: counted vmcnt (this iteration's 15 requests so far may fly, everything older has landed) + barrier = the other
-    // buffer is complete; RD0: the next iteration's sub-step-0 fragments from it (slots 88, 90, .. 118); lgkmcnt(0) behind the last MFMA.
+    // One 64-deep iteration on buffer X: 128 MFMAs, and between them -- RD1: the 16 fragment reads of sub-step 1 (slots 0 .. 15); B1 behind slot
+    // 20: lgkmcnt(0) + barrier = every wave is done with buffer X; the 16 DMA requests of the stage two iterations ahead into buffer X, spread wide
+    // (slots 22, 28, .. 112: a request every 6 MFMAs; every 3 from slot 42 measured 2 - 4 % slower at the four call sites, every 2 slower still:
+    // tools/gemm_w4_probe.hip schedules 1 / 41 / 42 - 47, gpurun_out/r4aa_w4.log, r4ab_w4.log); B2 behind slot 86: counted vmcnt (this iteration's 11
+    // requests so far may fly, everything older has landed) + barrier = the other buffer is complete; RD0: the next iteration's sub-step-0 fragments
+    // from it (slots 88, 90, .. 118); lgkmcnt(0) behind the last MFMA.
     // The main loop exists in few copies with straight-line control flow between them (a conditional INSIDE the iteration loop made the register
     // allocator shuffle and spill the 256 tied AccVGPR operands).  So nothing about an iteration is conditional: the last two iterations of the last tile
     // request the last tile's stages again (never read; the final vmcnt(0) in front of the epilogue retires them before the wave ends), and a
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto body = [&](auto xc, auto waitc) {
         constexpr int X = decltype(xc)::value;
         constexpr bool WAITV = decltype(waitc)::value;
-        constexpr int R1S = 2, B1P = 40, D0 = 42, DS = 3, B2P = 86, R0 = 88, R0S = 2;
+        constexpr int R1S = 1, B1P = 20, D0 = 22, DS = 6, B2P = 86, R0 = 88, R0S = 2;
         static_for<128>([&](auto nc) {
             (void)acc; (void)fw; (void)fa; (void)voffA; (void)voffW; (void)baseA; (void)baseW;
             constexpr int n = decltype(nc)::value;
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     dma16w(2 * OPB + X * OPB + wdst + (pc - 8) * 1024, voffW[pc - 8], baseW);
             }
             if constexpr (n == B2P) {
-                constexpr int issued = (B2P - D0) / DS + 1;  // this iteration's requests so far
+                constexpr int issued = (B2P - D0) / DS + 1 > 16 ? 16 : (B2P - D0) / DS + 1;  // this iteration's requests so far
                 if constexpr (WAITV)
                     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(issued) : "memory");
                 else
@@ -205,6 +207,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4_ACC(i, j) ([&]() -> f32x4 { asm volatile("" : "+a"(acc[i][j])); return acc[i][j]; }())
 
     // ---- store-only epilogue of one 64-feature half (= lean_epilogue of gemm_fast.hip for one of its waves)
+    // (Non-temporal stores -- what the vendor kernel uses -- measured: QKV - 6 % and FF2 - 6 % in isolation, FF1 + 3 %; in situ at C2 every
+    //  combination LOST 0.5 - 1 %: the kernels behind read the tile back.  gpurun_out/r4u_w4.log, r4z_ab.log.  Not kept.)
     [[maybe_unused]] auto store_half = [&](auto hc, auto actc) {
         constexpr int h = decltype(hc)::value, ACT = decltype(actc)::value;
         const int nb = n0 + wn * 128 + h * 64;
@@ -482,11 +486,12 @@ bool gemm_w4_ok(const GemmParams& p, int mode, int epi) {
     return false;
 }
 
-int launch_gemm_w4(const GemmParams& p, int epi, hipStream_t stream) {
-    const int tiles_n = p.N / 256, nblocks = (p.M / 256) * tiles_n;
+int launch_gemm_w4(const GemmParams& p0, int epi, hipStream_t stream) {
+    const int tiles_n = p0.N / 256, nblocks = (p0.M / 256) * tiles_n;
     const int pg = gemm_persist_grid();
     const dim3 grid(nblocks < pg ? nblocks : pg), block(256);
-    const bool lnf = p.lnf_stats != nullptr;
+    const bool lnf = p0.lnf_stats != nullptr;
+    const GemmParams& p = p0;
     if (epi == EPI_STORE_T && lnf)
         hipLaunchKernelGGL((gemm_w4_kernel<EPI_STORE_T, true>), grid, block, 0, stream, p, tiles_n, nblocks);
     else if (epi == EPI_STORE_T)

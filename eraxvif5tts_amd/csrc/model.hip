@@ -604,6 +604,8 @@ extern "C" int f5_plan_get_option(f5_plan_t p, const char* key, int* value) {
         *value = p->ragged_graph;
     else if (strcmp(key, "ln_fold_active") == 0)  // the staged time grid has a LayerNorm-fold table and the knob is on (what the next sample() runs)
         *value = (p->fold && g_ln_fold) ? 1 : 0;
+    else if (strcmp(key, "gemm_w4") == 0)  // the one-wave-per-SIMD kernel's knob (which launches take it: gemm_w4_ok, by shape)
+        *value = g_gemm_w4;
     else if (strcmp(key, "residual_fallbacks") == 0)
         *value = p->fallbacks;
     else if (strcmp(key, "residual_guard_amax_bits") == 0)  // diagnostic: float bits of the largest finite |element| the last event saw

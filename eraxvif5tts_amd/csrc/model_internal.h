@@ -219,7 +219,7 @@ int finish_if_pending(f5_plan_s* p);  // completes a deferred sample() before th
 
 
 // ---- eval_common.hip
-extern int g_w_prefetch, g_res_f16, g_ln_defer, g_resid_rmw, g_ln_fold, g_ln_fold_inkernel, g_ln_fold_fin, g_gemm_pad_rows, g_sync_evals;
+extern int g_w_prefetch, g_res_f16, g_ln_defer, g_resid_rmw, g_ln_fold, g_ln_fold_inkernel, g_ln_fold_fin, g_gemm_pad_rows, g_sync_evals, g_gemm_w4;
 bool plan_res_f16(const f5_plan_s* p);
 GemmParams gp_zero();
 int run_gemm(f5_plan_s* p, const GemmParams& g, int mode, int epi, hipStream_t st);

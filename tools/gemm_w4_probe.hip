@@ -136,8 +136,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // 17: MFMA stream alone, epilogue without its stores; 18: MFMA stream alone, half of the workgroups start half a tile late; 19: schedule 1
         // with that start skew; 20: schedule 1 without the stores
         constexpr bool NO_DMA = SCHED == 10 || SCHED == 12 || SCHED == 13 || SCHED == 17 || SCHED == 18, NO_RD = SCHED == 11 || NO_DMA && SCHED != 10, NO_BAR = SCHED == 13 || SCHED == 14 || SCHED == 17 || SCHED == 18;
-        constexpr int R1S = SCHED == 0 ? 3 : 2, B1P = SCHED == 0 ? 49 : 40, D0 = SCHED == 0 ? 50 : 42, DS = (SCHED == 2 || SCHED == 4) ? 2 : 3;
-        constexpr int B2P = SCHED == 0 ? 100 : (SCHED == 3 || SCHED == 4 ? 78 : 86), R0 = B2P + 2, R0S = SCHED == 0 ? 0 : 2;
+        constexpr bool M0E = SCHED == 40 || SCHED == 41;
+        constexpr bool S42 = SCHED >= 42 && SCHED <= 47;  // family of schedule 42: reads of sub-step 1 in the first 16 slots, requests spread wide
+        constexpr int R1S = SCHED == 0 ? 3 : (S42 ? 1 : 2), B1P = SCHED == 0 ? 49 : (S42 ? (SCHED == 46 ? 20 : 24) : 40), D0 = SCHED == 0 ? 50 : (S42 ? (SCHED == 46 ? 22 : 26) : 42), DS = (SCHED == 2 || SCHED == 4 || SCHED == 41) ? 2 : (SCHED == 43 ? 5 : (SCHED == 44 || SCHED == 46 ? 6 : (S42 ? 4 : 3)));
+        constexpr int B2P = SCHED == 0 ? 100 : (SCHED == 3 || SCHED == 4 ? 78 : (SCHED == 45 ? 104 : (SCHED == 47 ? 94 : 86))), R0 = B2P + 2, R0S = SCHED == 0 ? 0 : (SCHED == 45 ? 1 : 2);
         static_for<128>([&](auto nc) {
             (void)acc; (void)fw; (void)fa;
             constexpr int n = decltype(nc)::value;
@@ -147,7 +149,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if constexpr (n == B1P && !NO_BAR) {  // B1: every wave is done with buffer X
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
-            if constexpr (ISSUE && !NO_DMA && n >= D0 && n < D0 + 16 * DS && (n - D0) % DS == 0) {
+            if constexpr (M0E && ISSUE && n + 1 >= D0 && n + 1 < D0 + 16 * DS && (n + 1 - D0) % DS == 0) {  // M0 one slot ahead of its request
+                constexpr int pc = (n + 1 - D0) / DS;
+                const int dst = pc < 8 ? X * OPB + wdst + pc * 1024 : 2 * OPB + X * OPB + wdst + (pc - 8) * 1024;
+                asm volatile("s_mov_b32 m0, %0" ::"s"(dst));
+            }
+            if constexpr (M0E && ISSUE && n >= D0 && n < D0 + 16 * DS && (n - D0) % DS == 0) {
+                constexpr int pc = (n - D0) / DS;
+                if constexpr (pc < 8)
+                    asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voffA[pc]), "s"(baseA) : "memory");
+                else
+                    asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voffW[pc - 8]), "s"(baseW) : "memory");
+            }
+            if constexpr (!M0E && ISSUE && !NO_DMA && n >= D0 && n < D0 + 16 * DS && (n - D0) % DS == 0) {
                 constexpr int pc = (n - D0) / DS;
                 if constexpr (pc < 8)
                     dma(X * OPB + wdst + pc * 1024, voffA[pc], baseA);
@@ -182,7 +196,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int pc = 0; pc < 8; ++pc) dma(2 * OPB + X * OPB + wdst + pc * 1024, voffW[pc], baseW);
     };
-    if constexpr (SCHED == 18 || SCHED == 19) {
+    if constexpr (SCHED == 18 || SCHED == 19 || SCHED == 31) {
         if ((blockIdx.x >> 3) & 1)
             for (int i = 0; i < K / 340; ++i) __builtin_amdgcn_s_sleep(127);  // 64 x 127 cycles each: about half a tile at K = 1024
     }
@@ -200,19 +214,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     tile_mn(blockIdx.x, m0, n0);
     auto epilogue = [&]() {
         bf16_t* orow = C + (size_t)(m0 + wm * 128 + fr) * ldc + n0 + wn * 128 + 16 * (fq & 1) + 8 * (fq >> 1);
+        if constexpr (SCHED >= 30 && SCHED <= 34) {
+            // read-modify-write of the output tile (the in-place residual update of the library): 30 every load before the first store, 31 the
+            // same behind a half-tile start skew of every other workgroup, 32 loads only, 33 each step's loads just ahead of its stores
+            u32x4 xs[8][4];
+            if constexpr (SCHED != 33) {
+                static_for<8>([&](auto jc) {
+                    static_for<4>([&](auto hc) {
+                        constexpr int j = decltype(jc)::value, hh = decltype(hc)::value;
+                        xs[j][hh] = *reinterpret_cast<const u32x4*>(orow + (size_t)16 * j * ldc + 32 * hh);
+                    });
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            static_for<8>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<4>([&](auto hc) {
+                    constexpr int hh = decltype(hc)::value, i = hh * 2;
+                    if constexpr (SCHED == 33) xs[j][hh] = *reinterpret_cast<const u32x4*>(orow + (size_t)16 * j * ldc + 32 * hh);
+                    asm volatile("" : "+a"(acc[i][j]));
+                    asm volatile("" : "+a"(acc[i + 1][j]));
+                    const u32x4 x = xs[j][hh];
+                    f32x4 a = acc[i][j], b = acc[i + 1][j];
+                    a[0] += __builtin_bit_cast(float, x[0] << 16); a[1] += __builtin_bit_cast(float, x[0] & 0xffff0000u);
+                    a[2] += __builtin_bit_cast(float, x[1] << 16); a[3] += __builtin_bit_cast(float, x[1] & 0xffff0000u);
+                    b[0] += __builtin_bit_cast(float, x[2] << 16); b[1] += __builtin_bit_cast(float, x[2] & 0xffff0000u);
+                    b[2] += __builtin_bit_cast(float, x[3] << 16); b[3] += __builtin_bit_cast(float, x[3] & 0xffff0000u);
+                    const u32x4 q = pair_swap(to_bf16x4(a), to_bf16x4(b));
+                    if constexpr (SCHED == 32)
+                        asm volatile("" ::"v"(q));
+                    else
+                        *reinterpret_cast<u32x4*>(orow + (size_t)16 * j * ldc + 32 * hh) = q;
+                });
+            });
+            return;
+        }
         static_for<8>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             __builtin_amdgcn_sched_barrier(0);  // (keeps the accumulator reads of later token tiles from being hoisted: register pressure)
             static_for<4>([&](auto hc) {
                 constexpr int i = decltype(hc)::value * 2;
-                // (an empty volatile asm on the AccVGPR value: the AGPR -> VGPR copies of the C++ use below cannot be hoisted above it, i.e. the
-                //  compiler cannot read all 256 accumulators into VGPRs at the top of the epilogue and spill)
                 asm volatile("" : "+a"(acc[i][j]));
                 asm volatile("" : "+a"(acc[i + 1][j]));
                 const u32x4 q = pair_swap(to_bf16x4(acc[i][j]), to_bf16x4(acc[i + 1][j]));
                 if constexpr (SCHED == 17 || SCHED == 20)
                     asm volatile("" ::"v"(q));
-                else if constexpr (SCHED == 22 || SCHED == 23)  // non-temporal stores (what the vendor kernel uses)
+                else if constexpr (SCHED == 22 || SCHED == 23)
                     __builtin_nontemporal_store(q, reinterpret_cast<u32x4*>(orow + (size_t)16 * j * ldc + 32 * (i / 2)));
                 else
                     *reinterpret_cast<u32x4*>(orow + (size_t)16 * j * ldc + 32 * (i / 2)) = q;
@@ -268,7 +316,7 @@ static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u
 
 static void launch(int sched, dim3 grid, const bf16_t* dA, const bf16_t* dW, bf16_t* dC, int M, int N, int K, int tiles_n, int nblocks) {
 #define W4_CASE(S) case S: hipLaunchKernelGGL(w4_kernel<S>, grid, dim3(256), 0, 0, dA, dW, dC, M, N, K, K, K, N, tiles_n, nblocks, 8); break;
-    switch (sched) { W4_CASE(0) W4_CASE(1) W4_CASE(3) W4_CASE(10) W4_CASE(11) W4_CASE(12) W4_CASE(13) W4_CASE(14) W4_CASE(17) W4_CASE(18) W4_CASE(19) W4_CASE(20) W4_CASE(21) W4_CASE(22) W4_CASE(23) }
+    switch (sched) { W4_CASE(0) W4_CASE(1) W4_CASE(3) W4_CASE(10) W4_CASE(11) W4_CASE(12) W4_CASE(13) W4_CASE(14) W4_CASE(17) W4_CASE(18) W4_CASE(19) W4_CASE(20) W4_CASE(21) W4_CASE(22) W4_CASE(23) W4_CASE(30) W4_CASE(31) W4_CASE(32) W4_CASE(33) W4_CASE(40) W4_CASE(41) W4_CASE(42) W4_CASE(43) W4_CASE(44) W4_CASE(45) W4_CASE(46) W4_CASE(47) }
 }
 
 int main(int argc, char** argv) {
@@ -278,7 +326,7 @@ int main(int argc, char** argv) {
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     ncu = prop.multiProcessorCount & ~7;
-    for (int sched : {1, 21, 22, 23, 1, 22})
+    for (int sched : {42, 43, 44, 45, 46, 47, 42})
     for (const Shape& sh : shapes) {
         const int M = sh.M, N = sh.N, K = sh.K;
         std::vector<uint16_t> hA((size_t)M * K), hW((size_t)N * K);
@@ -334,7 +382,7 @@ int main(int argc, char** argv) {
             if (ms / 10 < best) best = ms / 10;
         }
         printf("[sched %d] %s M=%d N=%d K=%d: %.1f us = %.0f TF | max abs err %.4g (max |ref| %.3g)%s\n", sched, sh.name, M, N, K, best * 1e3, 2.0 * M * N * K / best / 1e9, maxerr, maxref,
-               (sched >= 10 && sched != 22) ? "  (timing only)" : (maxerr <= 0.02 * maxref + 1e-3 ? "" : "  <-- MISMATCH"));
+               (sched >= 10 && sched != 22 && sched < 40) ? "  (timing only)" : (maxerr <= 0.02 * maxref + 1e-3 ? "" : "  <-- MISMATCH"));
         fflush(stdout);
         (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dC); (void)hipFree(dRows); (void)hipFree(dRef);
     }

@@ -1,7 +1,7 @@
 """HBM-side traffic per launch of every hot kernel IN SITU: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate passes, counters
 only) over one eager two-step C2 sample() (tools/sample_one.py), averaged per kernel name.  FETCH_SIZE reads 1/2 on gfx950 (MI355X_MICROARCH.md).
    python tools/pmc_insitu_traffic.py collect <outdir> [bench args...]     python tools/pmc_insitu_traffic.py summarise <outdir> [qkv_traffic.json]
-With a json path, the in-situ figure of the fused QKV projection (round 4: the LayerNorm-fold build gemm_fast_kernel<256, 128, 0, 4, 30, 5, true>) is
+With a json path, the in-situ figure of the fused QKV projection (round 4: gemm_w4_kernel<4, true>, the one-wave-per-SIMD LayerNorm-fold build; before it gemm_fast_kernel<256, 128, 0, 4, 30, 5, true>) is
 written in the form bench.py reads for roofline.traffic."""
 import collections
 import csv
@@ -44,7 +44,8 @@ def summarise(outdir, json_out=None):
         print(f"{k[:70]:<70s} {n:8d} {fetch / 1e6:10.1f} {write / 1e6:10.1f} {tot / 1e6:10.1f}")
     if json_out:
         import json
-        qkv = [r for r in rows if "gemm_fast_kernel<256, 128, 0, 4, 30, 5, true>" in r[1]] or [r for r in rows if "gemm_fast_kernel<256, 128, 0, 4, 30, 5" in r[1]]
+        qkv = ([r for r in rows if "gemm_w4_kernel<4, true>" in r[1]] or [r for r in rows if "gemm_w4_kernel<4" in r[1]] or
+               [r for r in rows if "gemm_fast_kernel<256, 128, 0, 4, 30, 5, true>" in r[1]] or [r for r in rows if "gemm_fast_kernel<256, 128, 0, 4, 30, 5" in r[1]])
         if not qkv:
             sys.exit("no fused-QKV launch of the persistent kernel in the counter files")
         tot, k, n, fetch, write = qkv[0]
