@@ -202,9 +202,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             static_for<8>([&](auto jc) { acc[decltype(ic)::value][decltype(jc)::value] = b4[decltype(ic)::value]; });
         });
     };
-    // (an empty volatile asm on the AccVGPR value in front of every C++ use: the AGPR -> VGPR copies cannot be hoisted above it, so the compiler
-    //  cannot read all 256 accumulators into VGPRs at the top of the epilogue and spill)
-#define W4_ACC(i, j) ([&]() -> f32x4 { asm volatile("" : "+a"(acc[i][j])); return acc[i][j]; }())
+    // An accumulator reaches the vector ALU through four volatile v_accvgpr_read_b32 statements AT ITS USE.  Left to the compiler, the AGPR -> VGPR
+    // copies of all 256 sit directly behind the last MFMA (where the asm operand is defined) and spill; pinned by an empty asm("" : "+a"(acc)) in
+    // front of each use they stay put, but every tuple is first moved to one scratch AGPR tuple (4 v_accvgpr_mov_b32 per accumulator, 256 extra
+    // vector instructions per tile and wave: the first builds of this file).
+#define W4_ACC(i, j)                                                                         \
+    ([&]() -> f32x4 {                                                                        \
+        float c0_, c1_, c2_, c3_;                                                            \
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(c0_) : "a"(acc[i][j][0]));           \
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(c1_) : "a"(acc[i][j][1]));           \
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(c2_) : "a"(acc[i][j][2]));           \
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(c3_) : "a"(acc[i][j][3]));           \
+        return f32x4{c0_, c1_, c2_, c3_};                                                    \
+    }())
 
     // ---- store-only epilogue of one 64-feature half (= lean_epilogue of gemm_fast.hip for one of its waves)
     // (Non-temporal stores -- what the vendor kernel uses -- measured: QKV - 6 % and FF2 - 6 % in isolation, FF1 + 3 %; in situ at C2 every
