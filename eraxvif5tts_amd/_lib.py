@@ -7,7 +7,8 @@ import os
 import torch  # noqa: F401  (must be imported first: libf5hip resolves libamdhip64.so.7 to the runtime torch already loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libf5hip.so")
+# (F5HIP_LIB: developer override, another in-tree build of the library for same-box A/B runs of two builds)
+LIB_PATH = os.environ.get("F5HIP_LIB") or os.path.join(_HERE, "lib", "libf5hip.so")
 
 F5_PREC_BF16, F5_PREC_FP32 = 0, 1
 F5_ODE_EULER, F5_ODE_MIDPOINT = 0, 1

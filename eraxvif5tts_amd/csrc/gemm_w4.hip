@@ -187,12 +187,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         dma4w(ldst + 768, nb + 256u, p.lnf_c2);
         dma16w(ldst + 1024, (unsigned)((m0 + wm * 128 + 2 * lane) * 8), reinterpret_cast<const char*>(p.lnf_stats));  // lane l: rows 2l, 2l + 1
     };
-    [[maybe_unused]] auto lnf_apply = [&](const f32x4& a, int i, int j) {  // i: feature tile 0..7 of the wave, j: token tile
-        const f32x4 c1 = *reinterpret_cast<const f32x4*>(lnf_lds + (i * 16 + 4 * fq) * 4);
-        const f32x4 c2 = *reinterpret_cast<const f32x4*>(lnf_lds + 512 + (i * 16 + 4 * fq) * 4);
-        const f32x2 st = *reinterpret_cast<const f32x2*>(lnf_lds + 1024 + (j * 16 + fr) * 8);
-        return epi_lnf4(a, st[0], st[1], c1, c2);
-    };
     auto load_bias = [&](int tn0, f32x4 (&dst)[8]) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) dst[i] = *reinterpret_cast<const f32x4*>(p.bias + tn0 + wn * 128 + i * 16 + 4 * fq);
@@ -219,12 +213,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- store-only epilogue of one 64-feature half (= lean_epilogue of gemm_fast.hip for one of its waves)
     // (Non-temporal stores -- what the vendor kernel uses -- measured: QKV - 6 % and FF2 - 6 % in isolation, FF1 + 3 %; in situ at C2 every
     //  combination LOST 0.5 - 1 %: the kernels behind read the tile back.  gpurun_out/r4u_w4.log, r4z_ab.log.  Not kept.)
-    [[maybe_unused]] auto store_half = [&](auto hc, auto actc) {
+    // ROPE: this half is a q / k head that receives RoPE -- a wave-uniform property, taken as a BRANCH between two builds of the loop: in
+    // F5TTS_Base (pe_attn_head = 1) 2 of the 48 heads of q | k | v rotate, and with a per-element select (what the first builds of this file
+    // did, as the 8-wave kernel does) the other 46 paid for the rotation's 32 packed multiply-adds and 16 selects per step all the same.
+    [[maybe_unused]] auto store_half_impl = [&](auto hc, auto actc, auto ropec) {
         constexpr int h = decltype(hc)::value, ACT = decltype(actc)::value;
+        constexpr bool rope_wave = decltype(ropec)::value;
         const int nb = n0 + wn * 128 + h * 64;
         bf16_t* orow = reinterpret_cast<bf16_t*>(p.out_t) + (size_t)(m0 + wm * 128 + fr) * p.ldo + nb + 16 * (fq & 1) + 8 * (fq >> 1);
         const size_t jstride = (size_t)16 * p.ldo;
-        [[maybe_unused]] bool rope_wave = false;
         [[maybe_unused]] f32x4 rp[2][4];
         [[maybe_unused]] int pos0 = 0;
         auto load_rope = [&](auto jc, f32x4 (&dst)[4]) {
@@ -235,27 +232,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const f32x4*>(t + 16 * i);
         };
-        if constexpr (EPI == EPI_ROPE_T) {
-            const int part = nb / p.rope_inner;
-            rope_wave = part < 2 && ((nb - part * p.rope_inner) >> 6) < p.rope_heads;
+        if constexpr (rope_wave) {
             pos0 = (p.row0 + m0 + wm * 128 + fr) % p.rows_per_batch;
-            if (rope_wave) load_rope(std::integral_constant<int, 0>{}, rp[0]);
+            load_rope(std::integral_constant<int, 0>{}, rp[0]);
+        }
+        // LayerNorm fold: the half's column constants are read from the staging area ONCE (32 registers), a token tile's (mean, rstd) one tile
+        // ahead.  (Read inside lnf_apply -- per feature tile and token tile, as the 8-wave kernel does -- a lone wave waited for the LDS in front of
+        // every use: 12 reads and 8 waits per step.)
+        [[maybe_unused]] f32x4 c1h[4], c2h[4];
+        [[maybe_unused]] f32x2 stj[2];
+        if constexpr (LNF) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                c1h[ii] = *reinterpret_cast<const f32x4*>(lnf_lds + ((h * 4 + ii) * 16 + 4 * fq) * 4);
+                c2h[ii] = *reinterpret_cast<const f32x4*>(lnf_lds + 512 + ((h * 4 + ii) * 16 + 4 * fq) * 4);
+            }
+            stj[0] = *reinterpret_cast<const f32x2*>(lnf_lds + 1024 + fr * 8);
         }
         static_for<8>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (EPI == EPI_ROPE_T && j + 1 < 8) {
-                if (rope_wave) load_rope(std::integral_constant<int, j + 1>{}, rp[(j + 1) & 1]);
-            }
+            if constexpr (LNF && j + 1 < 8) stj[(j + 1) & 1] = *reinterpret_cast<const f32x2*>(lnf_lds + 1024 + ((j + 1) * 16 + fr) * 8);
+            if constexpr (rope_wave && j + 1 < 8) load_rope(std::integral_constant<int, j + 1>{}, rp[(j + 1) & 1]);
             f32x4 vals[4];
             static_for<4>([&](auto ic) {
                 constexpr int ii = decltype(ic)::value, i = h * 4 + ii;
                 f32x4 v = W4_ACC(i, j);
-                if constexpr (LNF) v = lnf_apply(v, i, j);
+                if constexpr (LNF) v = epi_lnf4(v, stj[j & 1][0], stj[j & 1][1], c1h[ii], c2h[ii]);
                 if constexpr (ACT == ACT_GELU_TANH) v = epi_gelu_tanh4(v);
-                if constexpr (EPI == EPI_ROPE_T) {
-                    if (rope_wave) v = epi_rope4(v, rp[j & 1][ii]);
-                }
+                if constexpr (rope_wave) v = epi_rope4(v, rp[j & 1][ii]);  // x_transformers apply_rotary_pos_emb: adjacent pairs, fp32 math
                 vals[ii] = v;
             });
             const u32x4 q0 = pair_swap(to_bf16x4(vals[0]), to_bf16x4(vals[1]));
@@ -264,6 +269,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             *reinterpret_cast<u32x4*>(o) = q0;
             *reinterpret_cast<u32x4*>(o + 32) = q1;
         });
+    };
+    [[maybe_unused]] auto store_half = [&](auto hc, auto actc) {
+        if constexpr (EPI == EPI_ROPE_T) {
+            const int nb = n0 + wn * 128 + decltype(hc)::value * 64;
+            const int part = nb / p.rope_inner;
+            if (part < 2 && ((nb - part * p.rope_inner) >> 6) < p.rope_heads) {
+                store_half_impl(hc, actc, std::true_type{});
+                return;
+            }
+        }
+        store_half_impl(hc, actc, std::false_type{});
     };
     // ---- in-place update of the fp16 residual stream (= lean_resid_f16 of gemm_fast.hip for two of its waves), with the LayerNorm fold's partial
     // row statistics of the values just stored.  bias[N] and gate[N] of the launch live in LDS (staged once at kernel start), not in registers, and
@@ -332,12 +348,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // partial row statistics: one scalar base per half, the row's 32-bit offset per token tile
         auto steps = [&](auto keptc) __attribute__((always_inline)) {
             constexpr bool ALL = decltype(keptc)::value;
+            f32x4 g4[4];  // the half's gate values, read from LDS once per half (inside the step a lone wave waits for them in front of their use)
             static_for<16>([&](auto sc) __attribute__((always_inline)) {
                 constexpr int h = decltype(sc)::value / 8, j = decltype(sc)::value % 8;
                 const int nb = n0 + wn * 128 + h * 64;
-                f32x4 g4[4];
+                if constexpr (j == 0) {
 #pragma unroll
-                for (int ii = 0; ii < 4; ++ii) g4[ii] = *reinterpret_cast<const f32x4*>(lds_gate + nb + ii * 16 + 4 * fq);
+                    for (int ii = 0; ii < 4; ++ii) g4[ii] = *reinterpret_cast<const f32x4*>(lds_gate + nb + ii * 16 + 4 * fq);
+                }
                 f32x4 x0, x1, x2, x3;
                 {
                     const u32x4 q = xs[h][j][0];  // inverse of pair_swap: this lane's 8 stored features -> the accumulator layout
