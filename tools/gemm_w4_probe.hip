@@ -126,7 +126,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     // one 64-deep iteration on buffer X.  ISSUE: the DMA front still has stages to request; WAITV: the next iteration's stage must be waited for
     // (not in a tile's first iteration: everything requested before the epilogue was waited for there).
-    auto body = [&](auto xc, auto issuec, auto waitc) {
+    // deferred stores (schedules 50 / 51): half of a tile's output stays in 64 registers and leaves during the NEXT tile's first four iterations
+    u32x4 dq[16];
+    const char* dbase = reinterpret_cast<const char*>(C);
+    unsigned doff[4] = {0u, 0u, 0u, 0u};
+    auto body = [&](auto xc, auto issuec, auto waitc, auto stc) {
+        constexpr int ST = decltype(stc)::value;  // -1: none, 0..3: this iteration stores dq[4 ST .. 4 ST + 3]
         constexpr int X = decltype(xc)::value;
         constexpr bool ISSUE = decltype(issuec)::value, WAITV = decltype(waitc)::value;
         // schedule: RD1 = the 16 fragment reads of sub-step 1 at MFMA slots R1S * k; B1 (lgkmcnt(0) + barrier) behind slot B1P; the 16 DMA requests at
@@ -137,8 +142,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // with that start skew; 20: schedule 1 without the stores
         constexpr bool NO_DMA = SCHED == 10 || SCHED == 12 || SCHED == 13 || SCHED == 17 || SCHED == 18, NO_RD = SCHED == 11 || NO_DMA && SCHED != 10, NO_BAR = SCHED == 13 || SCHED == 14 || SCHED == 17 || SCHED == 18;
         constexpr bool M0E = SCHED == 40 || SCHED == 41;
-        constexpr bool S42 = SCHED >= 42 && SCHED <= 47;  // family of schedule 42: reads of sub-step 1 in the first 16 slots, requests spread wide
-        constexpr int R1S = SCHED == 0 ? 3 : (S42 ? 1 : 2), B1P = SCHED == 0 ? 49 : (S42 ? (SCHED == 46 ? 20 : 24) : 40), D0 = SCHED == 0 ? 50 : (S42 ? (SCHED == 46 ? 22 : 26) : 42), DS = (SCHED == 2 || SCHED == 4 || SCHED == 41) ? 2 : (SCHED == 43 ? 5 : (SCHED == 44 || SCHED == 46 ? 6 : (S42 ? 4 : 3)));
+        constexpr bool S42 = (SCHED >= 42 && SCHED <= 47) || SCHED == 50 || SCHED == 51;  // family of schedule 42: reads of sub-step 1 in the first 16 slots, requests spread wide
+        constexpr int R1S = SCHED == 0 ? 3 : (S42 ? 1 : 2), B1P = SCHED == 0 ? 49 : (S42 ? ((SCHED == 46 || SCHED == 50) ? 20 : 24) : 40), D0 = SCHED == 0 ? 50 : (S42 ? ((SCHED == 46 || SCHED == 50) ? 22 : 26) : 42), DS = (SCHED == 2 || SCHED == 4 || SCHED == 41) ? 2 : (SCHED == 43 ? 5 : (SCHED == 44 || SCHED == 46 || SCHED == 50 ? 6 : (S42 ? 4 : 3)));
         constexpr int B2P = SCHED == 0 ? 100 : (SCHED == 3 || SCHED == 4 ? 78 : (SCHED == 45 ? 104 : (SCHED == 47 ? 94 : 86))), R0 = B2P + 2, R0S = SCHED == 0 ? 0 : (SCHED == 45 ? 1 : 2);
         static_for<128>([&](auto nc) {
             (void)acc; (void)fw; (void)fa;
@@ -184,6 +189,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if constexpr (!NO_RD && n >= R0 && n < R0 + 16 * R0S && (n - R0) % R0S == 0)
                     rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 1 - X>{}, std::integral_constant<int, (n - R0) / R0S>{});
             }
+            if constexpr (ST >= 0 && n >= 90 && n < 122 && (n - 90) % 8 == 0) {
+                constexpr int k = (n - 90) / 8;
+                (void)dq; (void)doff; (void)dbase;
+                if constexpr (k == 0) asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(doff[ST]), "v"(dq[4 * ST + 0]), "s"(dbase) : "memory");
+                if constexpr (k == 1) asm volatile("global_store_dwordx4 %0, %1, %2 offset:64" ::"v"(doff[ST]), "v"(dq[4 * ST + 1]), "s"(dbase) : "memory");
+                if constexpr (k == 2) asm volatile("global_store_dwordx4 %0, %1, %2 offset:128" ::"v"(doff[ST]), "v"(dq[4 * ST + 2]), "s"(dbase) : "memory");
+                if constexpr (k == 3) asm volatile("global_store_dwordx4 %0, %1, %2 offset:192" ::"v"(doff[ST]), "v"(dq[4 * ST + 3]), "s"(dbase) : "memory");
+            }
             if constexpr (n == 127) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         });
         if constexpr (ISSUE) front_advance();
@@ -214,6 +227,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     tile_mn(blockIdx.x, m0, n0);
     auto epilogue = [&]() {
         bf16_t* orow = C + (size_t)(m0 + wm * 128 + fr) * ldc + n0 + wn * 128 + 16 * (fq & 1) + 8 * (fq >> 1);
+        if constexpr (SCHED == 50 || SCHED == 51) {
+            // token tiles 0..3 leave now, 4..7 are kept (already packed) for the next tile's iterations 0..3
+            static_for<8>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<4>([&](auto hc) {
+                    constexpr int i = decltype(hc)::value * 2;
+                    asm volatile("" : "+a"(acc[i][j]));
+                    asm volatile("" : "+a"(acc[i + 1][j]));
+                    const u32x4 q = pair_swap(to_bf16x4(acc[i][j]), to_bf16x4(acc[i + 1][j]));
+                    if constexpr (j < 4)
+                        *reinterpret_cast<u32x4*>(orow + (size_t)16 * j * ldc + 32 * (i / 2)) = q;
+                    else
+                        dq[(j - 4) * 4 + i / 2] = q;
+                });
+            });
+            dbase = reinterpret_cast<const char*>(C + (size_t)(m0 + wm * 128) * ldc + n0 + wn * 128);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) doff[jj] = (unsigned)(((fr + 16 * (jj + 4)) * ldc + 16 * (fq & 1) + 8 * (fq >> 1)) * 2);
+            return;
+        }
         if constexpr (SCHED >= 30 && SCHED <= 34) {
             // read-modify-write of the output tile (the in-place residual update of the library): 30 every load before the first store, 31 the
             // same behind a half-tile start skew of every other workgroup, 32 loads only, 33 each step's loads just ahead of its stores
@@ -272,25 +306,59 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     using X0 = std::integral_constant<int, 0>;
     using X1 = std::integral_constant<int, 1>;
     // a tile: nk iterations (nk even, >= 4), buffer = kt & 1; only the last two iterations of the last tile request nothing
+    using N1 = std::integral_constant<int, -1>;
+    if constexpr (SCHED == 50 || SCHED == 51) {
+        auto flush = [&]() {  // the kept half leaves at once (after the last tile)
+            static_for<16>([&](auto ec) {
+                constexpr int e = decltype(ec)::value;
+                *reinterpret_cast<u32x4*>(const_cast<char*>(dbase) + doff[e / 4] + 64 * (e % 4)) = dq[e];
+            });
+        };
+        for (int t = 0; t < my_tiles; ++t) {
+            const bool last = t + 1 == my_tiles;
+            if (t == 0) {
+                body(X0{}, T{}, T{}, N1{});
+                body(X1{}, T{}, T{}, N1{});
+                body(X0{}, T{}, T{}, N1{});
+                body(X1{}, T{}, T{}, N1{});
+            } else {
+                body(X0{}, T{}, F{}, std::integral_constant<int, 0>{});
+                body(X1{}, T{}, T{}, std::integral_constant<int, 1>{});
+                body(X0{}, T{}, T{}, std::integral_constant<int, 2>{});
+                body(X1{}, T{}, T{}, std::integral_constant<int, 3>{});
+            }
+            const int kend = last ? nk - 2 : nk;
+            for (int kt = 4; kt < kend; kt += 2) {
+                body(X0{}, T{}, T{}, N1{});
+                body(X1{}, T{}, T{}, N1{});
+            }
+            if (last) {
+                body(X0{}, F{}, T{}, N1{});
+                body(X1{}, F{}, T{}, N1{});
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            epilogue();
+            zero_acc();
+            if (!last) tile_mn(blockIdx.x + (t + 1) * G, m0, n0);
+        }
+        flush();
+        return;
+    }
     for (int t = 0; t < my_tiles; ++t) {
         const bool last = t + 1 == my_tiles;
         if (t == 0)
-            body(X0{}, T{}, T{});  // (the very first iteration waits: stage 1 was requested just now)
+            body(X0{}, T{}, T{}, N1{});  // (the very first iteration waits: stage 1 was requested just now)
         else
-            body(X0{}, T{}, F{});
-        if constexpr (SCHED == 21 || SCHED == 23) {  // 21 / 23: timing only, no wait in a tile's second iteration either
-            if (t == 0) body(X1{}, T{}, T{}); else body(X1{}, T{}, F{});
-        } else {
-            body(X1{}, T{}, T{});
-        }
+            body(X0{}, T{}, F{}, N1{});
+        body(X1{}, T{}, T{}, N1{});
         const int kend = last ? nk - 2 : nk;
         for (int kt = 2; kt < kend; kt += 2) {
-            body(X0{}, T{}, T{});
-            body(X1{}, T{}, T{});
+            body(X0{}, T{}, T{}, N1{});
+            body(X1{}, T{}, T{}, N1{});
         }
         if (last) {
-            body(X0{}, F{}, T{});
-            body(X1{}, F{}, T{});
+            body(X0{}, F{}, T{}, N1{});
+            body(X1{}, F{}, T{}, N1{});
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stages requested ahead have landed; only stores follow
         epilogue();
@@ -316,7 +384,7 @@ static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u
 
 static void launch(int sched, dim3 grid, const bf16_t* dA, const bf16_t* dW, bf16_t* dC, int M, int N, int K, int tiles_n, int nblocks) {
 #define W4_CASE(S) case S: hipLaunchKernelGGL(w4_kernel<S>, grid, dim3(256), 0, 0, dA, dW, dC, M, N, K, K, K, N, tiles_n, nblocks, 8); break;
-    switch (sched) { W4_CASE(0) W4_CASE(1) W4_CASE(3) W4_CASE(10) W4_CASE(11) W4_CASE(12) W4_CASE(13) W4_CASE(14) W4_CASE(17) W4_CASE(18) W4_CASE(19) W4_CASE(20) W4_CASE(21) W4_CASE(22) W4_CASE(23) W4_CASE(30) W4_CASE(31) W4_CASE(32) W4_CASE(33) W4_CASE(40) W4_CASE(41) W4_CASE(42) W4_CASE(43) W4_CASE(44) W4_CASE(45) W4_CASE(46) W4_CASE(47) }
+    switch (sched) { W4_CASE(0) W4_CASE(1) W4_CASE(3) W4_CASE(10) W4_CASE(11) W4_CASE(12) W4_CASE(13) W4_CASE(14) W4_CASE(17) W4_CASE(18) W4_CASE(19) W4_CASE(20) W4_CASE(21) W4_CASE(22) W4_CASE(23) W4_CASE(30) W4_CASE(31) W4_CASE(32) W4_CASE(33) W4_CASE(40) W4_CASE(41) W4_CASE(42) W4_CASE(43) W4_CASE(44) W4_CASE(45) W4_CASE(46) W4_CASE(47) W4_CASE(50) }
 }
 
 int main(int argc, char** argv) {
@@ -326,7 +394,7 @@ int main(int argc, char** argv) {
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     ncu = prop.multiProcessorCount & ~7;
-    for (int sched : {42, 43, 44, 45, 46, 47, 42})
+    for (int sched : {46, 50, 46, 50})
     for (const Shape& sh : shapes) {
         const int M = sh.M, N = sh.N, K = sh.K;
         std::vector<uint16_t> hA((size_t)M * K), hW((size_t)N * K);
