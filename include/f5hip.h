@@ -33,7 +33,7 @@ extern "C" {
 /* the library is built with -fvisibility=hidden: only the entry points declared here are exported */
 #define F5_API __attribute__((visibility("default")))
 
-#define F5HIP_VERSION 302 /* 0.3.2: + f5_sample_ragged, f5_mmdit_forward, f5_duration_predict_g; f5_duration_weights grew (cond_w, cond_b, gin_channels) */
+#define F5HIP_VERSION 400 /* 0.4.0 (round 4): + the BigVGAN entry points and mel front-end, f5_op_ln_fold, bounded timing ring; plan options "ln_fold_active", "gemm_w4"; tuning keys "ln_fold", "ln_fold_fin", "gemm_w4"; 0.3.2: + f5_sample_ragged, f5_mmdit_forward, f5_duration_predict_g */
 
 /* error codes */
 #define F5_OK 0

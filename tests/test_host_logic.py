@@ -68,7 +68,7 @@ def test_c_abi_exports_every_declared_symbol():
     missing = [n for n in declared if not hasattr(lib, n)]
     assert not missing, missing
     assert sorted(_lib.EXPORTS) == declared
-    assert lib.f5_version() == 302
+    assert lib.f5_version() == 400
 
 
 def test_product_path_fails_loudly_without_gpu():
