@@ -174,8 +174,9 @@ int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, const float
         // (round 3, late: any token count whose q|k tiles fit one round while q|k|v would need a second -- ragged batches, odd batch sizes:
         //  M = 6144: 288 tiles of 256 x 256 = two rounds, 60 us; 192 + 192 narrower ones: 53 us.  Same sums either way.)
         const int tiles_m = (rows + 255) / 256, ncu = f5_cu_count();
+        // (not when the one-wave-per-SIMD kernel takes the whole fused projection: its 128-row tiles give every CU a whole number of tiles there)
         const bool split_v = P == F5_PREC_BF16 && p->gemm_kernel != 0 && inner % 256 == 0 && tiles_m * (2 * inner / 256) <= ncu &&
-                             tiles_m * (3 * inner / 256) > ncu && tiles_m * (2 * inner / 256) >= 160;
+                             tiles_m * (3 * inner / 256) > ncu && tiles_m * (2 * inner / 256) >= 160 && !(!c.qk_norm && gemm_w4_ok(g, GEMM_DENSE, EPI_ROPE_T));
         if (c.qk_norm) {  // q, k stored as projected; RMSNorm per head, then RoPE, in place (modules.py:463-475)
             g.rope = nullptr;
             g.rope_inner = g.rope_heads = 0;

@@ -105,6 +105,8 @@ bool gemm_fast_lnf_inkernel(const GemmParams& p);
 // LayerNorm fold: true when an in-place residual launch with these parameters can finish its row statistics inside the launch
 // (GemmParams::fin_counter): every schedule but the PERSISTENT one, which leaves them to stats_finalize_kernel
 bool gemm_fast_resid_finishes(const GemmParams& p);
+// true when a dense launch with these parameters runs on the one-wave-per-SIMD kernel (gemm_w4.hip): whole tiles, at least one per CU, lean operand forms
+bool gemm_w4_ok(const GemmParams& p, int mode, int epi);
 // dedicated kernel for the dim-1024 grouped Conv1d(k = 31) of ConvPositionEmbedding (conv31.hip); GemmParams as for GEMM_CONV31
 bool conv31_supported(const GemmParams& p, int precision, int epi);
 int launch_conv31(const GemmParams& p, hipStream_t stream);

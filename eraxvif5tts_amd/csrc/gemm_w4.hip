@@ -29,15 +29,21 @@
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 
 namespace {
-constexpr int OPB = 32768;          // one operand of one stage: 256 rows x 128 bytes
-constexpr int EPI_LDS = 4 * OPB;    // behind the stage buffers: the LayerNorm fold's epilogue operands (4 waves x 2 KiB), or bias[N] | gate[N] of an in-place residual launch
-constexpr int EPI_LDS_BYTES = 16384;
+constexpr int OPB = 32768;          // the weight operand of one stage: 256 rows x 128 bytes
+constexpr int EPI_LDS_BYTES = 16384;  // behind the stage buffers: the LayerNorm fold's epilogue operands (4 waves x 2 KiB), or bias[N] | gate[N] of an in-place residual launch
 
-template <int EPI, bool LNF>
+// MI: token tiles (of 16 rows) per wave.  8: the 256 x 256 tile (128 x 128 per wave, 128 MFMAs per iteration).  4: a 128 x 256 tile (64 x 128 per wave, 128
+// accumulator registers, 64 MFMAs per iteration) for launches that have no 256-row tile for every CU but a 128-row one (batches of 2 - 4 utterances).
+template <int EPI, bool LNF, int MI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_w4_kernel(GemmParams p, int tiles_n, int nblocks) {
     static_assert(EPI == EPI_STORE_T || EPI == EPI_ROPE_T || EPI == EPI_RESID, "block linears only");
     static_assert(!LNF || EPI != EPI_RESID, "LayerNorm fold: QKV (+ RoPE) and FF1 (+ GELU)");
-    __shared__ __attribute__((aligned(1024))) char smem[4 * OPB + EPI_LDS_BYTES];
+    static_assert(MI == 8 || MI == 4, "token tiles per wave");
+    constexpr int WROWS = MI * 16, BM = 2 * WROWS;  // token rows per wave / per tile
+    constexpr int OPA = BM * 128;                   // the activation operand of one stage
+    constexpr int WBASE = 2 * OPA, EPI_LDS = 2 * OPA + 2 * OPB;  // LDS: [A buffer 0][A buffer 1][W buffer 0][W buffer 1][epilogue operands]
+    constexpr int NP = MI + 8, NR = MI + 8, NMF = 16 * MI;       // requests per wave, fragment reads per sub-step, MFMAs per iteration
+    __shared__ __attribute__((aligned(1024))) char smem[EPI_LDS + EPI_LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -53,22 +59,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int gsz = min(gm, tiles_m_all - grp * gm);
         const int rin = swz - grp * gm * tiles_n;
         const int tile_n = rin / gsz, tile_m = grp * gm + (rin - tile_n * gsz);
-        tm0 = tile_m * 256;
+        tm0 = tile_m * BM;
         tn0 = tile_n * 256;
     };
     const int G = gridDim.x;
     const int my_tiles = (nblocks - (int)blockIdx.x + G - 1) / G;
     const int nk = p.K / 64;
 
-    // ---- DMA: per iteration this wave moves pieces wave * 8 + jj (jj = 0..7) of the activation tile and of the weight tile; a piece is 8 rows x 128
+    // ---- DMA: per iteration this wave moves pieces wave * MI + jj of the activation tile and wave * 8 + jj of the weight tile; a piece is 8 rows x 128
     // bytes (lane l -> row l >> 3, physical chunk l & 7).  Per-lane byte offsets are constant, the tile and the K position sit in two scalar bases.
-    unsigned voffA[8], voffW[8];
+    unsigned voffA[MI], voffW[8];
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
         const int row = (wave * 8 + jj) * 8 + (lane >> 3);
         const int logical = (lane & 7) ^ ((row >> 1) & 7);
-        voffA[jj] = (unsigned)(row * p.lda * 2 + logical * 16);
         voffW[jj] = (unsigned)(row * p.ldw * 2 + logical * 16);
+    }
+#pragma unroll
+    for (int jj = 0; jj < MI; ++jj) {
+        const int row = (wave * MI + jj) * 8 + (lane >> 3);
+        const int logical = (lane & 7) ^ ((row >> 1) & 7);
+        voffA[jj] = (unsigned)(row * p.lda * 2 + logical * 16);
     }
     const char* baseA;
     const char* baseW;
@@ -81,7 +92,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     front_tile();
     const unsigned lds0 = (unsigned)(size_t)smem;
-    const int wdst = (int)lds0 + wave * 8192;  // this wave's pieces inside an operand buffer
+    const int wdstA = (int)lds0 + wave * MI * 1024, wdstW = (int)lds0 + WBASE + wave * 8192;  // this wave's pieces inside an operand buffer
     // (s_nop: one wait state between the scalar write of M0 and the LDS-DMA that reads it; the hazard recogniser does not look inside an asm)
     auto dma16w = [&](int ldsdst, unsigned voff, const char* base) {
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsdst), "v"(voff), "s"(base) : "memory");
@@ -106,21 +117,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     // ---- fragment read addresses (LDS byte addresses; the 16-row tile index and the buffer are immediate offsets).  Layout: [A buffer 0][A buffer 1]
     // [W buffer 0][W buffer 1]
-    const unsigned ra0 = lds0 + (unsigned)((wm * 128 + fr) * 128 + ((fq ^ (fr >> 1)) * 16));  // sub-step 0: chunks 0..3
-    const unsigned ra1 = ra0 ^ 64u;                                                             // sub-step 1: chunks 4..7
-    const unsigned rw0 = lds0 + 2 * OPB + (unsigned)((wn * 128 + fr) * 128 + ((fq ^ (fr >> 1)) * 16));
+    const unsigned ra0 = lds0 + (unsigned)((wm * WROWS + fr) * 128 + ((fq ^ (fr >> 1)) * 16));  // sub-step 0: chunks 0..3
+    const unsigned ra1 = ra0 ^ 64u;                                                               // sub-step 1: chunks 4..7
+    const unsigned rw0 = lds0 + WBASE + (unsigned)((wn * 128 + fr) * 128 + ((fq ^ (fr >> 1)) * 16));
     const unsigned rw1 = rw0 ^ 64u;
 
-    f32x4 acc[8][8];  // [feature tile][token tile], AccVGPRs
-    f32x4 fw[2][8], fa[2][8];
+    f32x4 acc[8][MI];  // [feature tile][token tile], AccVGPRs
+    f32x4 fw[2][8], fa[2][MI];
 #define W4_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-    auto rd = [&](auto sc, auto xc, auto ec) {  // fragment e (0..7 weight tiles, 8..15 token tiles) of sub-step S from buffer X
+    auto rd = [&](auto sc, auto xc, auto ec) {  // fragment e (0..7 weight tiles, 8..8 + MI - 1 token tiles) of sub-step S from buffer X
         constexpr int S = decltype(sc)::value, X = decltype(xc)::value, e = decltype(ec)::value;
         (void)fw; (void)fa; (void)ra0; (void)ra1; (void)rw0; (void)rw1;  // (asm operands alone do not capture inside a generic lambda)
         if constexpr (e < 8) {
             if constexpr (S == 0) W4_DSR(fw[0][e], rw0, X * OPB + e * 2048); else W4_DSR(fw[1][e], rw1, X * OPB + e * 2048);
         } else {
-            if constexpr (S == 0) W4_DSR(fa[0][e - 8], ra0, X * OPB + (e - 8) * 2048); else W4_DSR(fa[1][e - 8], ra1, X * OPB + (e - 8) * 2048);
+            if constexpr (S == 0) W4_DSR(fa[0][e - 8], ra0, X * OPA + (e - 8) * 2048); else W4_DSR(fa[1][e - 8], ra1, X * OPA + (e - 8) * 2048);
         }
     };
     // One 64-deep iteration on buffer X: 128 MFMAs, and between them -- RD1: the 16 fragment reads of sub-step 1 (slots 0 .. 15); B1 behind slot
@@ -138,34 +149,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto body = [&](auto xc, auto waitc) {
         constexpr int X = decltype(xc)::value;
         constexpr bool WAITV = decltype(waitc)::value;
-        constexpr int R1S = 1, B1P = 20, D0 = 22, DS = 6, B2P = 86, R0 = 88, R0S = 2;
-        static_for<128>([&](auto nc) {
+        // (MI = 4, 64 MFMAs: 12 reads in slots 0..11, B1 behind 13, 12 requests at 14, 18, .. 58, B2 behind 42, the next reads at 44..55)
+        constexpr int R1S = 1, B1P = MI == 8 ? 20 : 13, D0 = MI == 8 ? 22 : 14, DS = MI == 8 ? 6 : 4, B2P = MI == 8 ? 86 : 42, R0 = MI == 8 ? 88 : 44,
+                      R0S = MI == 8 ? 2 : 1;
+        static_for<NMF>([&](auto nc) {
             (void)acc; (void)fw; (void)fa; (void)voffA; (void)voffW; (void)baseA; (void)baseW;
             constexpr int n = decltype(nc)::value;
-            constexpr int s = n / 64, i = (n % 64) / 8, j = n % 8;
+            constexpr int s = n / (8 * MI), i = (n % (8 * MI)) / MI, j = n % MI;
             if constexpr (LNF)
                 asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fw[s][i]), "v"(fa[s][j]));
             else
                 asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fw[s][i]), "v"(fa[s][j]));
-            if constexpr (n < 16 * R1S && n % R1S == 0) rd(std::integral_constant<int, 1>{}, xc, std::integral_constant<int, n / R1S>{});
+            if constexpr (n < NR * R1S && n % R1S == 0) rd(std::integral_constant<int, 1>{}, xc, std::integral_constant<int, n / R1S>{});
             if constexpr (n == B1P) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if constexpr (n >= D0 && n < D0 + 16 * DS && (n - D0) % DS == 0) {
+            if constexpr (n >= D0 && n < D0 + NP * DS && (n - D0) % DS == 0) {
                 constexpr int pc = (n - D0) / DS;
-                if constexpr (pc < 8)
-                    dma16w(X * OPB + wdst + pc * 1024, voffA[pc], baseA);
+                if constexpr (pc < MI)
+                    dma16w(X * OPA + wdstA + pc * 1024, voffA[pc], baseA);
                 else
-                    dma16w(2 * OPB + X * OPB + wdst + (pc - 8) * 1024, voffW[pc - 8], baseW);
+                    dma16w(X * OPB + wdstW + (pc - MI) * 1024, voffW[pc - MI], baseW);
             }
             if constexpr (n == B2P) {
-                constexpr int issued = (B2P - D0) / DS + 1 > 16 ? 16 : (B2P - D0) / DS + 1;  // this iteration's requests so far
+                constexpr int issued = (B2P - D0) / DS + 1 > NP ? NP : (B2P - D0) / DS + 1;  // this iteration's requests so far
                 if constexpr (WAITV)
                     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(issued) : "memory");
                 else
                     asm volatile("s_barrier" ::: "memory");
             }
-            if constexpr (n >= R0 && n < R0 + 16 * R0S && (n - R0) % R0S == 0)
+            if constexpr (n >= R0 && n < R0 + NR * R0S && (n - R0) % R0S == 0)
                 rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 1 - X>{}, std::integral_constant<int, (n - R0) / R0S>{});
-            if constexpr (n == 127) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (n == NMF - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         });
         front_advance();
     };
@@ -185,7 +198,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         dma4w(ldst + 256, nb + 256u, p.lnf_c1);
         dma4w(ldst + 512, nb, p.lnf_c2);
         dma4w(ldst + 768, nb + 256u, p.lnf_c2);
-        dma16w(ldst + 1024, (unsigned)((m0 + wm * 128 + 2 * lane) * 8), reinterpret_cast<const char*>(p.lnf_stats));  // lane l: rows 2l, 2l + 1
+        // lane l: rows 2l, 2l + 1 of the wave's (MI = 4: 64 rows past the wave's own ride along; the statistics buffer is padded by 256 rows)
+        dma16w(ldst + 1024, (unsigned)((m0 + wm * WROWS + 2 * lane) * 8), reinterpret_cast<const char*>(p.lnf_stats));
     };
     auto load_bias = [&](int tn0, f32x4 (&dst)[8]) {
 #pragma unroll
@@ -193,7 +207,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     auto acc_from = [&](const f32x4 (&b4)[8]) {  // every accumulator starts from its feature's bias (gemm_fast.hip: init_acc)
         static_for<8>([&](auto ic) {
-            static_for<8>([&](auto jc) { acc[decltype(ic)::value][decltype(jc)::value] = b4[decltype(ic)::value]; });
+            static_for<MI>([&](auto jc) { acc[decltype(ic)::value][decltype(jc)::value] = b4[decltype(ic)::value]; });
         });
     };
     // An accumulator reaches the vector ALU through four volatile v_accvgpr_read_b32 statements AT ITS USE.  Left to the compiler, the AGPR -> VGPR
@@ -220,7 +234,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr int h = decltype(hc)::value, ACT = decltype(actc)::value;
         constexpr bool rope_wave = decltype(ropec)::value;
         const int nb = n0 + wn * 128 + h * 64;
-        bf16_t* orow = reinterpret_cast<bf16_t*>(p.out_t) + (size_t)(m0 + wm * 128 + fr) * p.ldo + nb + 16 * (fq & 1) + 8 * (fq >> 1);
+        bf16_t* orow = reinterpret_cast<bf16_t*>(p.out_t) + (size_t)(m0 + wm * WROWS + fr) * p.ldo + nb + 16 * (fq & 1) + 8 * (fq >> 1);
         const size_t jstride = (size_t)16 * p.ldo;
         [[maybe_unused]] f32x4 rp[2][4];
         [[maybe_unused]] int pos0 = 0;
@@ -233,7 +247,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const f32x4*>(t + 16 * i);
         };
         if constexpr (rope_wave) {
-            pos0 = (p.row0 + m0 + wm * 128 + fr) % p.rows_per_batch;
+            pos0 = (p.row0 + m0 + wm * WROWS + fr) % p.rows_per_batch;
             load_rope(std::integral_constant<int, 0>{}, rp[0]);
         }
         // LayerNorm fold: the half's column constants are read from the staging area ONCE (32 registers), a token tile's (mean, rstd) one tile
@@ -249,11 +263,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             stj[0] = *reinterpret_cast<const f32x2*>(lnf_lds + 1024 + fr * 8);
         }
-        static_for<8>([&](auto jc) {
+        static_for<MI>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (LNF && j + 1 < 8) stj[(j + 1) & 1] = *reinterpret_cast<const f32x2*>(lnf_lds + 1024 + ((j + 1) * 16 + fr) * 8);
-            if constexpr (rope_wave && j + 1 < 8) load_rope(std::integral_constant<int, j + 1>{}, rp[(j + 1) & 1]);
+            if constexpr (LNF && j + 1 < MI) stj[(j + 1) & 1] = *reinterpret_cast<const f32x2*>(lnf_lds + 1024 + ((j + 1) * 16 + fr) * 8);
+            if constexpr (rope_wave && j + 1 < MI) load_rope(std::integral_constant<int, j + 1>{}, rp[(j + 1) & 1]);
             f32x4 vals[4];
             static_for<4>([&](auto ic) {
                 constexpr int ii = decltype(ic)::value, i = h * 4 + ii;
@@ -298,7 +312,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(t), "+v"(z));
         const float tot = t + z;
         if (fq < 2) {
-            char* sb = reinterpret_cast<char*>(p.stats_out + ((size_t)(nb >> 6) * p.stats_ld + (m0 + wm * 128)) * 2);  // (scalar base + 32-bit lane offset)
+            char* sb = reinterpret_cast<char*>(p.stats_out + ((size_t)(nb >> 6) * p.stats_ld + (m0 + wm * WROWS)) * 2);  // (scalar base + 32-bit lane offset)
             *reinterpret_cast<float*>(sb + (unsigned)((m * 2 + fq) * 4)) = tot;
         }
     };
@@ -309,31 +323,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         asm volatile("" : "+v"(fr), "+v"(fq));
         // (one scalar base + eight 32-bit lane offsets, one per token tile; halves and feature-tile pairs are immediates: 64-bit addresses per
         //  access would cost 64 registers here)
-        char* const sbase = reinterpret_cast<char*>(p.out_f) + ((size_t)(m0 + wm * 128) * p.ldof + n0 + wn * 128) * 2;
-        unsigned offj[8];
+        char* const sbase = reinterpret_cast<char*>(p.out_f) + ((size_t)(m0 + wm * WROWS) * p.ldof + n0 + wn * 128) * 2;
+        unsigned offj[MI];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) offj[j] = (unsigned)(((fr + 16 * j) * p.ldof + 16 * (fq & 1) + 8 * (fq >> 1)) * 2);
+        for (int j = 0; j < MI; ++j) offj[j] = (unsigned)(((fr + 16 * j) * p.ldof + 16 * (fq & 1) + 8 * (fq >> 1)) * 2);
         unsigned keepbits = 0xffu;
-        if (p.rowmask && p.rowbits) keepbits = (unsigned)p.rowbits[((m0 + wm * 128) >> 7) * 16 + fr];
-        float piv[8];
+        if (p.rowmask && p.rowbits) keepbits = ((unsigned)p.rowbits[((m0 + wm * WROWS) >> 7) * 16 + fr] >> (((m0 + wm * WROWS) & 127) >> 4)) & ((1u << MI) - 1u);
+        float piv[MI];
         if (p.stats_out) {
-            const float* pbase = p.stats_pivot ? p.stats_pivot + (size_t)(m0 + wm * 128) * 2 : nullptr;  // (scalar base + 32-bit lane offset)
+            const float* pbase = p.stats_pivot ? p.stats_pivot + (size_t)(m0 + wm * WROWS) * 2 : nullptr;  // (scalar base + 32-bit lane offset)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) piv[j] = pbase ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pbase) + (unsigned)((fr + 16 * j) * 8)) : 0.0f;
+            for (int j = 0; j < MI; ++j) piv[j] = pbase ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pbase) + (unsigned)((fr + 16 * j) * 8)) : 0.0f;
         }
         // A lone wave cannot hide a load behind another wave's work: the stream tile is requested AHEAD (half, token tile) steps = 2 AHEAD loads
         // ahead of its use -- the first AHEAD before the first store, the others one by one behind a step's stores (a load issued behind a store also
         // waits for that store, vmcnt retires in order; AHEAD steps later the store is long acknowledged).  More than 6 spills accumulators.
-        u32x4 xs[2][8][2];  // [half][token tile][feature-tile pair]: the stream tile as stored (8 fp16 per lane and entry)
+        u32x4 xs[2][MI][2];  // [half][token tile][feature-tile pair]: the stream tile as stored (8 fp16 per lane and entry)
         auto load_step = [&](auto sc) __attribute__((always_inline)) {
-            constexpr int h = decltype(sc)::value / 8, j = decltype(sc)::value % 8;
+            constexpr int h = decltype(sc)::value / MI, j = decltype(sc)::value % MI;
             xs[h][j][0] = *reinterpret_cast<const u32x4*>(sbase + offj[j] + h * 128);
             xs[h][j][1] = *reinterpret_cast<const u32x4*>(sbase + offj[j] + h * 128 + 64);
         };
         constexpr int AHEAD = 4;
         static_for<AHEAD>([&](auto sc) { load_step(sc); });
         __builtin_amdgcn_sched_barrier(0);
-        const bool all_kept = __builtin_amdgcn_ballot_w64(keepbits != 0xffu) == 0ull;  // wave-uniform: no masked row in this wave's 128 token rows
+        const bool all_kept = __builtin_amdgcn_ballot_w64(keepbits != ((1u << MI) - 1u)) == 0ull;  // wave-uniform: no masked row in this wave's 128 token rows
         auto widen_h = [](unsigned lo, unsigned hi) __attribute__((always_inline)) {
             const f16x4_t hv = __builtin_bit_cast(f16x4_t, u32x2{lo, hi});
             return f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
@@ -349,8 +363,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         auto steps = [&](auto keptc) __attribute__((always_inline)) {
             constexpr bool ALL = decltype(keptc)::value;
             f32x4 g4[4];  // the half's gate values, read from LDS once per half (inside the step a lone wave waits for them in front of their use)
-            static_for<16>([&](auto sc) __attribute__((always_inline)) {
-                constexpr int h = decltype(sc)::value / 8, j = decltype(sc)::value % 8;
+            static_for<2 * MI>([&](auto sc) __attribute__((always_inline)) {
+                constexpr int h = decltype(sc)::value / MI, j = decltype(sc)::value % MI;
                 const int nb = n0 + wn * 128 + h * 64;
                 if constexpr (j == 0) {
 #pragma unroll
@@ -384,7 +398,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 *reinterpret_cast<u32x4*>(sbase + offj[j] + h * 128) = pair_swap(__builtin_bit_cast(bf16x4, h0), __builtin_bit_cast(bf16x4, h1));
                 *reinterpret_cast<u32x4*>(sbase + offj[j] + h * 128 + 64) = pair_swap(__builtin_bit_cast(bf16x4, h2), __builtin_bit_cast(bf16x4, h3));
                 if (p.stats_out) emit_stats(nb, fr + 16 * j, piv[j], h_f32(h0), h_f32(h1), h_f32(h2), h_f32(h3));
-                if constexpr (decltype(sc)::value + AHEAD < 16) load_step(std::integral_constant<int, decltype(sc)::value + AHEAD>{});
+                if constexpr (decltype(sc)::value + AHEAD < 2 * MI) load_step(std::integral_constant<int, decltype(sc)::value + AHEAD>{});
                 __builtin_amdgcn_sched_barrier(0);
             });
         };
@@ -404,9 +418,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- prologue: stages 0 and 1 requested, stage 0 landed, first fragments read
     auto issue_all = [&](int X) {
 #pragma unroll
-        for (int pc = 0; pc < 8; ++pc) dma16w(X * OPB + wdst + pc * 1024, voffA[pc], baseA);
+        for (int pc = 0; pc < MI; ++pc) dma16w(X * OPA + wdstA + pc * 1024, voffA[pc], baseA);
 #pragma unroll
-        for (int pc = 0; pc < 8; ++pc) dma16w(2 * OPB + X * OPB + wdst + pc * 1024, voffW[pc], baseW);
+        for (int pc = 0; pc < 8; ++pc) dma16w(X * OPB + wdstW + pc * 1024, voffW[pc], baseW);
     };
     issue_all(0);
     front_advance();
@@ -422,8 +436,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     acc_from(bstart);
     if constexpr (EPI == EPI_RESID) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this thread's part of the bias / gate image is written)
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LNF ? 21 : 16) : "memory");  // stage 0 has landed for everyone
-    static_for<16>([&](auto ec) { rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, ec); });
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LNF ? NP + 5 : NP) : "memory");  // stage 0 has landed for everyone
+    static_for<NR>([&](auto ec) { rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, ec); });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     // a tile: nk iterations (nk even, >= 4), buffer = iteration & 1
@@ -477,7 +491,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         n0 = nn0;
         if (!last) {
             // the next tile's first fragments (its stage 0 sits in buffer 0: nk is even), and its fold operands
-            static_for<16>([&](auto ec) { rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, ec); });
+            static_for<NR>([&](auto ec) { rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, ec); });
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (also: the epilogue's reads of the staging area are done before it is rewritten)
             if constexpr (LNF) stage_lnf();
         }
@@ -487,14 +501,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 }  // namespace
 
-int g_gemm_w4 = 1;  // tuning knob ("gemm_w4"): 1 = whole-tile block linears with at least one 256 x 256 tile per CU run on the one-wave-per-SIMD kernel
+int g_gemm_w4 = 1;  // tuning knob ("gemm_w4"): 1 = whole-tile block linears with at least one tile per CU run on the one-wave-per-SIMD kernel
+int g_gemm_w4_bm = 0;  // diagnostic knob ("gemm_w4_bm"): token rows per tile, 0 = by tile count, 128 / 256 forced where the shape allows
 
 int gemm_persist_grid();  // gemm_fast.hip
 
+// token rows per tile of this launch on the one-wave-per-SIMD kernel (0: the launch does not take it).  256 wherever that gives every CU a tile -- even
+// exactly one: measured against two 128-row tiles per CU at 8 x 1024 frames, out-projection 42.7 against 48.5 us, FF2 62.2 against 70.5 (the smaller tile
+// moves 1.5 x the operand bytes per FLOP through LDS) -- and 128 where only that fills the CUs (4 x 1024: out-projection / FF2 with 256 tiles of 128 x 256,
+// FF2 39.1 against 44.0 us on the 8-wave kernel's 256 x 128 tiles; 2 x 1024: the fused projection 34.2 against 37.2, FF1 23.3 against 27.2).
+// gpurun_out/r4ak_ab.log.
+static int w4_tile_rows(const GemmParams& p) {
+    const int pg = gemm_persist_grid();
+    const int t256 = p.M % 256 == 0 ? (p.M / 256) * (p.N / 256) : 0, t128 = p.M % 128 == 0 ? (p.M / 128) * (p.N / 256) : 0;
+    if (g_gemm_w4_bm == 256) return t256 >= pg ? 256 : 0;
+    if (g_gemm_w4_bm == 128) return t128 >= pg ? 128 : 0;
+    if (t256 >= pg) return 256;
+    return t128 >= pg ? 128 : 0;
+}
+
 bool gemm_w4_ok(const GemmParams& p, int mode, int epi) {
     if (!g_gemm_w4 || mode != GEMM_DENSE) return false;
-    if (p.M % 256 != 0 || p.N % 256 != 0 || p.K % 128 != 0 || p.K < 256 || (p.lda & 7) || (p.ldw & 7) || p.a_row_mod != 0 || p.row0 != 0) return false;
-    if ((p.M / 256) * (p.N / 256) < gemm_persist_grid()) return false;  // small launches: the 8-wave kernel's narrower tiles
+    if (p.N % 256 != 0 || p.K % 128 != 0 || p.K < 256 || (p.lda & 7) || (p.ldw & 7) || p.a_row_mod != 0 || p.row0 != 0) return false;
+    if (w4_tile_rows(p) == 0) return false;  // small launches: the 8-wave kernel's narrower tiles
     if ((size_t)255 * (size_t)(p.lda > p.ldw ? p.lda : p.ldw) * 2 + 128 > 0x7fffffffull) return false;
     if (p.lnf_partial || p.fin_counter || p.pf_n[0] || p.pf_n[1]) return false;
     const bool lnf = p.lnf_stats != nullptr;
@@ -514,24 +543,27 @@ bool gemm_w4_ok(const GemmParams& p, int mode, int epi) {
     return false;
 }
 
-int launch_gemm_w4(const GemmParams& p0, int epi, hipStream_t stream) {
-    const int tiles_n = p0.N / 256, nblocks = (p0.M / 256) * tiles_n;
+template <int MI> static int launch_w4(const GemmParams& p, int epi, hipStream_t stream) {
+    const int tiles_n = p.N / 256, nblocks = (p.M / (MI * 32)) * tiles_n;
     const int pg = gemm_persist_grid();
     const dim3 grid(nblocks < pg ? nblocks : pg), block(256);
-    const bool lnf = p0.lnf_stats != nullptr;
-    const GemmParams& p = p0;
+    const bool lnf = p.lnf_stats != nullptr;
     if (epi == EPI_STORE_T && lnf)
-        hipLaunchKernelGGL((gemm_w4_kernel<EPI_STORE_T, true>), grid, block, 0, stream, p, tiles_n, nblocks);
+        hipLaunchKernelGGL((gemm_w4_kernel<EPI_STORE_T, true, MI>), grid, block, 0, stream, p, tiles_n, nblocks);
     else if (epi == EPI_STORE_T)
-        hipLaunchKernelGGL((gemm_w4_kernel<EPI_STORE_T, false>), grid, block, 0, stream, p, tiles_n, nblocks);
+        hipLaunchKernelGGL((gemm_w4_kernel<EPI_STORE_T, false, MI>), grid, block, 0, stream, p, tiles_n, nblocks);
     else if (epi == EPI_ROPE_T && lnf)
-        hipLaunchKernelGGL((gemm_w4_kernel<EPI_ROPE_T, true>), grid, block, 0, stream, p, tiles_n, nblocks);
+        hipLaunchKernelGGL((gemm_w4_kernel<EPI_ROPE_T, true, MI>), grid, block, 0, stream, p, tiles_n, nblocks);
     else if (epi == EPI_ROPE_T)
-        hipLaunchKernelGGL((gemm_w4_kernel<EPI_ROPE_T, false>), grid, block, 0, stream, p, tiles_n, nblocks);
+        hipLaunchKernelGGL((gemm_w4_kernel<EPI_ROPE_T, false, MI>), grid, block, 0, stream, p, tiles_n, nblocks);
     else if (epi == EPI_RESID)
-        hipLaunchKernelGGL((gemm_w4_kernel<EPI_RESID, false>), grid, block, 0, stream, p, tiles_n, nblocks);
+        hipLaunchKernelGGL((gemm_w4_kernel<EPI_RESID, false, MI>), grid, block, 0, stream, p, tiles_n, nblocks);
     else
         return f5_fail(F5_EINVAL, "gemm_w4: unsupported epilogue %d", epi);
     F5_LAUNCH_CHECK();
     return 0;
+}
+
+int launch_gemm_w4(const GemmParams& p, int epi, hipStream_t stream) {
+    return w4_tile_rows(p) == 128 ? launch_w4<4>(p, epi, stream) : launch_w4<8>(p, epi, stream);
 }

@@ -525,13 +525,17 @@ def _with_knob(lib, key, value, fn):
         _lib.check(lib.f5_tuning_set(key, 1))
 
 
+@pytest.mark.parametrize("bm", [256, 128], ids=["256_row_tiles", "128_row_tiles"])
 @pytest.mark.parametrize("epi_name,shape,seq", [("store", (8192, 2048, 256), 0), ("store", (8192, 2048, 1024), 0), ("rope", (8192, 3072, 384), 1024),
-                                                ("rope", (16384, 1536, 1024), 2048), ("resid", (16384, 1024, 512), 0), ("resid_masked", (16384, 1024, 2048), 0)])
-def test_w4_kernel_equals_the_8_wave_kernel(epi_name, shape, seq):
+                                                ("rope", (16384, 1536, 1024), 2048), ("resid", (16384, 1024, 512), 0), ("resid_masked", (16384, 1024, 2048), 0),
+                                                ("resid_masked", (8320, 1024, 256), 0)])
+def test_w4_kernel_equals_the_8_wave_kernel(bm, epi_name, shape, seq):
     """Round 4, late: whole-tile block linears with at least one 256 x 256 tile per CU run on the one-wave-per-SIMD kernel (csrc/gemm_w4.hip: four
     waves, 128 x 128 outputs per wave, 64-deep stages refilled in place, hand-placed main loop).  Same MFMA, K order, start value and epilogue
     arithmetic as the 8-wave persistent kernel, so the outputs must agree BIT FOR BIT (knob gemm_w4 = 0 selects the 8-wave kernel) -- store + GELU,
-    QKV + RoPE (first head / all heads), the in-place fp16 residual update with and without a row mask -- and both agree with fp64."""
+    QKV + RoPE (first head / all heads), the in-place fp16 residual update with and without a row mask -- and both agree with fp64.  Both tile
+    heights of the kernel (knob gemm_w4_bm: 256 x 256 with 128 x 128 per wave, 128 x 256 with 64 x 128 per wave; a shape the forced height cannot
+    fill the CUs with falls back to the 8-wave kernel, M = 8320 is a multiple of 128 only)."""
     import gpu_helpers as G
     from eraxvif5tts_amd import _lib
     lib = _lib.load()
@@ -556,14 +560,19 @@ def test_w4_kernel_equals_the_8_wave_kernel(epi_name, shape, seq):
             rope, heads = torch.stack([ang.cos(), ang.sin()], dim=-1), (1 if N == 3072 else N // 3 // 64)
         run = lambda: G.op_linear_fused(1, epi, A, W, b, act, None, None, rope, heads, seq)
         ref, tol = _fused_ref(epi, A, W, b, act, None, None, rope, heads, seq), 3e-3
-    new = run()
+    _lib.check(lib.f5_tuning_set(b"gemm_w4_bm", bm))
+    try:
+        new = run()
+    finally:
+        _lib.check(lib.f5_tuning_set(b"gemm_w4_bm", 0))
     old = _with_knob(lib, b"gemm_w4", 0, run)
     assert rel_l2(new, ref) < tol and rel_l2(old, ref) < tol
     assert torch.equal(new, old)
 
 
+@pytest.mark.parametrize("bm", [256, 128], ids=["256_row_tiles", "128_row_tiles"])
 @pytest.mark.parametrize("N,Kb,epi", [(3072, 1024, 4), (2048, 2048, 0), (3072, 1024, -16)])
-def test_w4_kernel_layernorm_fold_site_equals_the_8_wave_kernel(N, Kb, epi):
+def test_w4_kernel_layernorm_fold_site_equals_the_8_wave_kernel(bm, N, Kb, epi):
     """The LayerNorm fold of one call site at a size the one-wave-per-SIMD kernel takes (M = 16 384 token rows: producer 64 x 4, consumer 64 x 8 / 12
     tiles): in-place residual epilogue with partial row statistics -> statistics -> fp16-operand projection with the fold epilogue (+ RoPE / GELU).
     Stream, statistics and output bit for bit against the 8-wave kernel (gemm_w4 = 0)."""
@@ -588,7 +597,11 @@ def test_w4_kernel_layernorm_fold_site_equals_the_8_wave_kernel(N, Kb, epi):
         rope = torch.stack([ang.cos(), ang.sin()], dim=-1).reshape(seq, 64).float()
     run = lambda: G.op_ln_fold(epi, x, A, Wo, bo, gate, W, bias, scale, shift, pivot=None, act="gelu_tanh" if epi == 0 else "none", rope=rope,
                                rope_heads=rope_heads, seq=seq)
-    new = run()
+    _lib.check(lib.f5_tuning_set(b"gemm_w4_bm", bm))
+    try:
+        new = run()
+    finally:
+        _lib.check(lib.f5_tuning_set(b"gemm_w4_bm", 0))
     old = _with_knob(lib, b"gemm_w4", 0, run)
     for a, c in zip(new, old):
         assert torch.isfinite(a).all() and torch.equal(a, c)
