@@ -241,8 +241,8 @@ def insitu_kernels(model, cfm, batch, B, N, nfe, args):
     _lib.check(lib.f5_plan_get_option(plan, b"ln_fold_active", C.byref(fold)), "plan_get_option")
     _lib.check(lib.f5_plan_get_option(plan, b"gemm_w4", C.byref(w4)), "plan_get_option")
     # (csrc/gemm_w4.hip, w4_tile_rows: whole 256- or 128-row tiles, at least one per CU -- the fused projection has 12 feature tiles per token tile)
-    insitu_kernels.w4 = bool(w4.value) and args.precision == "bf16" and ((rows % 256 == 0 and (rows // 256) * 12 >= 256) or
-                                                                         (rows % 128 == 0 and (rows // 128) * 12 >= 256))
+    insitu_kernels.w4 = bool(w4.value) and args.precision == "bf16" and ((rows % 256 == 0 and (rows // 256) * 12 * 4 >= 3 * 256) or
+                                                                         (rows % 128 == 0 and (rows // 128) * 12 * 2 >= 256))
     es = 2 if args.precision == "bf16" else 4
     xs = es  # storage bytes of a residual-stream element: fp16 in the bf16 production mode (blocks 1..21 of 22; the first reads fp32), fp32 otherwise
     work = {  # algorithmic work per launch: FLOP for the MFMA-bound kernels, bytes for the HBM-bound ones

@@ -22,7 +22,7 @@
 //     as gemm_fast.hip's persistent build: a wave's 128 features are treated as two 64-feature halves = two "waves" of that kernel, so the output
 //     bits do not depend on which of the two kernels a launch takes (tests/test_gpu_ops.py::test_w4_kernel_equals_the_8_wave_kernel).
 // Launch conditions (launch_gemm_w4_ok): bf16 / fp16-fold operands, M % 256 == 0, N % 256 == 0, K % 128 == 0, K >= 256, the lean operand forms
-// of the persistent 8-wave build, at least one tile per CU.
+// of the persistent 8-wave build, and enough tiles for the CUs (w4_tile_rows: 256-row tiles from three quarters of the CUs on, else 128-row tiles from half).
 #include "gemm_tile.h"
 #include "lnf_stats_math.h"
 
@@ -501,23 +501,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 }  // namespace
 
-int g_gemm_w4 = 1;  // tuning knob ("gemm_w4"): 1 = whole-tile block linears with at least one tile per CU run on the one-wave-per-SIMD kernel
+int g_gemm_w4 = 1;  // tuning knob ("gemm_w4"): 1 = whole-tile block linears with enough tiles for the CUs (w4_tile_rows) run on the one-wave-per-SIMD kernel
 int g_gemm_w4_bm = 0;  // diagnostic knob ("gemm_w4_bm"): token rows per tile, 0 = by tile count, 128 / 256 forced where the shape allows
 
 int gemm_persist_grid();  // gemm_fast.hip
 
-// token rows per tile of this launch on the one-wave-per-SIMD kernel (0: the launch does not take it).  256 wherever that gives every CU a tile -- even
-// exactly one: measured against two 128-row tiles per CU at 8 x 1024 frames, out-projection 42.7 against 48.5 us, FF2 62.2 against 70.5 (the smaller tile
-// moves 1.5 x the operand bytes per FLOP through LDS) -- and 128 where only that fills the CUs (4 x 1024: out-projection / FF2 with 256 tiles of 128 x 256,
-// FF2 39.1 against 44.0 us on the 8-wave kernel's 256 x 128 tiles; 2 x 1024: the fused projection 34.2 against 37.2, FF1 23.3 against 27.2).
-// gpurun_out/r4ak_ab.log.
+// token rows per tile of this launch on the one-wave-per-SIMD kernel (0: the launch does not take it).  Measured at 1 - 16 utterances x 1024 frames
+// (gpurun_out/r4ak_ab.log, r4am_ab.log; t256 / t128 = tiles of the two heights, as a share of the CUs):
+//   * 256 rows wherever they reach three quarters of the CUs -- the tall tile wins even with a quarter of the CUs idle against the short one on all of
+//     them (3 x 1024 FF1: 192 tall tiles 32.7 us, 384 short ones 34.3; 8 x 1024 out-projection: 256 tall 42.7, 512 short 48.5: the short tile moves
+//     1.5 x the operand bytes per FLOP through LDS) -- but not at half (4 x 1024 FF2: 128 tall tiles 50.3 us, 256 short ones 37.5);
+//   * otherwise 128 rows from half the CUs on (1 x 1024: the fused projection on 192 short tiles 20.2 against 25.8 us on the 8-wave kernel's narrow
+//     tiles, FF1 on 128 short tiles 18.4 against 21.0) -- not at a quarter (1 x 1024 FF2: 30.7 against 24.9).
 static int w4_tile_rows(const GemmParams& p) {
     const int pg = gemm_persist_grid();
     const int t256 = p.M % 256 == 0 ? (p.M / 256) * (p.N / 256) : 0, t128 = p.M % 128 == 0 ? (p.M / 128) * (p.N / 256) : 0;
     if (g_gemm_w4_bm == 256) return t256 >= pg ? 256 : 0;
     if (g_gemm_w4_bm == 128) return t128 >= pg ? 128 : 0;
-    if (t256 >= pg) return 256;
-    return t128 >= pg ? 128 : 0;
+    if (4 * t256 >= 3 * pg) return 256;
+    return 2 * t128 >= pg ? 128 : 0;
 }
 
 bool gemm_w4_ok(const GemmParams& p, int mode, int epi) {

@@ -585,6 +585,9 @@ def test_ragged_chunks_equal_serial_chunks_and_are_faster():
     assert tr < ts / 1.5
 
 
+_C1_ORACLE = {}
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_c1_config_matches_oracle(prec):
     """BASELINE.json configs[0] -- the reference's own CPU-runnable case: F5TTS_Base random-init, ONE utterance, seq_len 256, NFE 8, CFG
@@ -600,8 +603,14 @@ def test_c1_config_matches_oracle(prec):
     cond, text, lens, dur = bench.synth_batch(1, 256, "cuda", seed=3)
     g = torch.Generator().manual_seed(5)
     y0 = torch.randn(1, 256, 100, generator=g)
-    ref, _ = cpu_ref.sample(W, bench.BASE_ARCH, cond.cpu(), text.cpu(), dur.cpu(), lens=lens.cpu(), steps=8, cfg_strength=1.0, sway_sampling_coef=-1.0,
-                            y0=y0, return_trajectory=False)
+    # (the oracle run is the same for both precisions -- same seeded weights, inputs and noise -- and the costliest host-side step of the suite:
+    #  computed once per session, keyed by a digest of the weights it ran on)
+    key = tuple(round(float(W[k].double().abs().sum()), 3) for k in sorted(W)[:8]) + (len(W),)
+    if _C1_ORACLE.get("key") != key:
+        _C1_ORACLE["ref"], _ = cpu_ref.sample(W, bench.BASE_ARCH, cond.cpu(), text.cpu(), dur.cpu(), lens=lens.cpu(), steps=8, cfg_strength=1.0,
+                                              sway_sampling_coef=-1.0, y0=y0, return_trajectory=False)
+        _C1_ORACLE["key"] = key
+    ref = _C1_ORACLE["ref"]
     tol = {"fp32": 2e-4, "bf16": 2e-2}[prec]
     for use_graph in (False, True, True):
         out, _ = cfm.sample(cond=cond, text=text, duration=dur, lens=lens, steps=8, cfg_strength=1.0, sway_sampling_coef=-1.0, y0=y0.cuda(),
