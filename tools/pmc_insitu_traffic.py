@@ -44,7 +44,7 @@ def summarise(outdir, json_out=None):
         print(f"{k[:70]:<70s} {n:8d} {fetch / 1e6:10.1f} {write / 1e6:10.1f} {tot / 1e6:10.1f}")
     if json_out:
         import json
-        qkv = ([r for r in rows if "gemm_w4_kernel<4, true>" in r[1]] or [r for r in rows if "gemm_w4_kernel<4" in r[1]] or
+        qkv = ([r for r in rows if "gemm_w4_kernel<4, true" in r[1]] or [r for r in rows if "gemm_w4_kernel<4" in r[1]] or
                [r for r in rows if "gemm_fast_kernel<256, 128, 0, 4, 30, 5, true>" in r[1]] or [r for r in rows if "gemm_fast_kernel<256, 128, 0, 4, 30, 5" in r[1]])
         if not qkv:
             sys.exit("no fused-QKV launch of the persistent kernel in the counter files")
