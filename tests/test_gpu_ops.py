@@ -525,6 +525,34 @@ def _with_knob(lib, key, value, fn):
         _lib.check(lib.f5_tuning_set(key, 1))
 
 
+@pytest.mark.parametrize("epi_name,shape,seq", [("rope", (2048, 3072, 1024), 1024), ("store", (2048, 2048, 1024), 0), ("resid", (6144, 1024, 2048), 0),
+                                                ("store", (6144, 2048, 1024), 0)])
+def test_w4_kernel_on_partly_filled_grids(epi_name, shape, seq):
+    """Small batches: the launcher gives a launch to the one-wave-per-SIMD kernel from three quarters of the CUs on (256-row tiles) or from half
+    (128-row tiles) -- single-utterance projections (192 / 128 short tiles), three utterances' FF1 (192 tall tiles) and FF2 (192 short ones).  A
+    workgroup then walks one tile and the request front re-walks it past the end; outputs bit for bit as the 8-wave kernel's."""
+    import gpu_helpers as G
+    from eraxvif5tts_amd import _lib
+    lib = _lib.load()
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + 11 * N + K)
+    A, W, b = G.bf16_round(torch.randn(M, K, generator=g)), G.bf16_round(torch.randn(N, K, generator=g) / math.sqrt(K)), torch.randn(N, generator=g)
+    if epi_name == "resid":
+        gate = torch.randn(N, generator=g)
+        x = (torch.randn(M, N, generator=g) * 3).half().float()
+        run = lambda: G.op_linear_fused(1, G.EPI_RESID, A, W, b, "none", gate, None, stream_in=x)
+    else:
+        epi = {"store": G.EPI_STORE_T, "rope": G.EPI_ROPE_T}[epi_name]
+        rope, heads = None, 0
+        if epi_name == "rope":
+            ang = torch.rand(seq, 32, generator=g) * 6.28
+            rope, heads = torch.stack([ang.cos(), ang.sin()], dim=-1), 1
+        run = lambda: G.op_linear_fused(1, epi, A, W, b, "gelu_tanh" if epi_name == "store" else "none", None, None, rope, heads, seq)
+    new = run()
+    old = _with_knob(lib, b"gemm_w4", 0, run)
+    assert torch.isfinite(new).all() and torch.equal(new, old)
+
+
 @pytest.mark.parametrize("bm", [256, 128], ids=["256_row_tiles", "128_row_tiles"])
 @pytest.mark.parametrize("epi_name,shape,seq", [("store", (8192, 2048, 256), 0), ("store", (8192, 2048, 1024), 0), ("rope", (8192, 3072, 384), 1024),
                                                 ("rope", (16384, 1536, 1024), 2048), ("resid", (16384, 1024, 512), 0), ("resid_masked", (16384, 1024, 2048), 0),
