@@ -84,6 +84,17 @@ int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, const float
         t.N = ff;
         ink_ff1 = gemm_fast_lnf_inkernel(t);
     }
+    // ... and on the one-wave-per-SIMD kernel's 128-row tiles the consumer finishes the statistics by default (gemm_w4.hip: finish_stats; small
+    // batches, where the two statistics launches of a block were 13 of its 102 us).  Only where the 8-wave kernel could take the launch in the
+    // same form, should the other kernel refuse it.
+    if (lnf && p->lnf_stats2 && !c.qk_norm) {
+        GemmParams t = gp_zero();
+        t.M = rows_g; t.K = D; t.lda = D; t.ldw = D;
+        t.N = 3 * inner;
+        if (!ink_qkv && gemm_w4_lnf_inkernel(rows_g, 3 * inner, D) && gemm_fast_lnf_inkernel(t)) ink_qkv = true;
+        t.N = ff;
+        if (!ink_ff1 && gemm_w4_lnf_inkernel(rows_g, ff, D) && gemm_fast_lnf_inkernel(t)) ink_ff1 = true;
+    }
     // producer side of site k (out-projection, FF2): the non-persistent schedules (small batches) finish the statistics inside the launch -- the
     // workgroup that completes a block of token rows last turns the partial sums into (mean, rstd), carries the range guard and leaves nothing
     // for a statistics launch to do (gemm.h: fin_counter; same bits as stats_finalize_kernel)

@@ -25,12 +25,14 @@
 // of the persistent 8-wave build, and enough tiles for the CUs (w4_tile_rows: 256-row tiles from three quarters of the CUs on, else 128-row tiles from half).
 #include "gemm_tile.h"
 #include "lnf_stats_math.h"
+#include <string.h>
 
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 
 namespace {
 constexpr int OPB = 32768;          // the weight operand of one stage: 256 rows x 128 bytes
-constexpr int EPI_LDS_BYTES = 16384;  // behind the stage buffers: the LayerNorm fold's epilogue operands (4 waves x 2 KiB), or bias[N] | gate[N] of an in-place residual launch
+constexpr int EPI_LDS_BYTES = 16384;  // behind the stage buffers: the LayerNorm fold's epilogue operands (4 waves x 2 KiB; 4 x 11 KiB on the 128-row tile, which can
+                                      // finish the row statistics itself), or bias[N] | gate[N] of an in-place residual launch
 
 // MI: token tiles (of 16 rows) per wave.  8: the 256 x 256 tile (128 x 128 per wave, 128 MFMAs per iteration).  4: a 128 x 256 tile (64 x 128 per wave, 128
 // accumulator registers, 64 MFMAs per iteration) for launches that have no 256-row tile for every CU but a 128-row one (batches of 2 - 4 utterances).
@@ -43,7 +45,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int OPA = BM * 128;                   // the activation operand of one stage
     constexpr int WBASE = 2 * OPA, EPI_LDS = 2 * OPA + 2 * OPB;  // LDS: [A buffer 0][A buffer 1][W buffer 0][W buffer 1][epilogue operands]
     constexpr int NP = MI + 8, NR = MI + 8, NMF = 16 * MI;       // requests per wave, fragment reads per sub-step, MFMAs per iteration
-    __shared__ __attribute__((aligned(1024))) char smem[EPI_LDS + EPI_LDS_BYTES];
+    constexpr int LNF_AREA = MI == 4 ? 11264 : 2048;  // per wave: c1[128] | c2[128] | (mean, rstd)[128 rows] (| 16 partial planes x 64 rows | pivots of 64 rows)
+    constexpr int EPI_BYTES = 4 * LNF_AREA > EPI_LDS_BYTES ? 4 * LNF_AREA : EPI_LDS_BYTES;
+    __shared__ __attribute__((aligned(1024))) char smem[EPI_LDS + EPI_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -62,6 +66,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         tm0 = tile_m * BM;
         tn0 = tile_n * 256;
     };
+    // weight prefetch for the launches BEHIND this one (GemmParams::pf_p; small batches: every block's weights come from HBM again, and with the
+    // statistics finished inside the consumer there is no statistics launch left to do it): thread t of workgroup b touches lines (2 b + r) 256 + t,
+    // one dword each.  The loads are the oldest entries of the vector-memory queue and their values are looked at behind the last epilogue only.
+    [[maybe_unused]] unsigned pfv[4] = {0u, 0u, 0u, 0u};
+    if constexpr (MI == 4) {
+        if (p.pf_n[0] | p.pf_n[1]) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const size_t line = ((size_t)blockIdx.x * 2 + r) * 256u + tid;
+                if (line * 128u < p.pf_n[0]) pfv[r] = *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.pf_p[0]) + line * 128u);
+                if (line * 128u < p.pf_n[1]) pfv[2 + r] = *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.pf_p[1]) + line * 128u);
+            }
+        }
+    }
     const int G = gridDim.x;
     const int my_tiles = (nblocks - (int)blockIdx.x + G - 1) / G;
     const int nk = p.K / 64;
@@ -190,16 +208,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- per-tile epilogue operands
     int m0, n0;
     tile_mn(blockIdx.x, m0, n0);
-    char* const lnf_lds = smem + EPI_LDS + wave * 2048;  // LNF: c1[128] | c2[128] | (mean, rstd)[128 rows] of this wave, by LDS-DMA at the start of a tile
+    char* const lnf_lds = smem + EPI_LDS + wave * LNF_AREA;  // LNF: c1[128] | c2[128] | (mean, rstd)[128 rows] of this wave, by LDS-DMA at the start of a tile
     [[maybe_unused]] auto stage_lnf = [&]() {
-        const int ldst = (int)lds0 + EPI_LDS + wave * 2048;
+        const int ldst = (int)lds0 + EPI_LDS + wave * LNF_AREA;
         const unsigned nb = (unsigned)(n0 + wn * 128 + lane) * 4u;
         dma4w(ldst, nb, p.lnf_c1);
         dma4w(ldst + 256, nb + 256u, p.lnf_c1);
         dma4w(ldst + 512, nb, p.lnf_c2);
         dma4w(ldst + 768, nb + 256u, p.lnf_c2);
+        if constexpr (MI == 4) {
+            if (p.lnf_partial) {
+                // statistics finished by THIS kernel (gemm.h: lnf_partial; single-utterance launches, where the two statistics launches of a block
+                // were 13 of its 102 us): the producer's 16 partial planes of the wave's 64 rows and the rows' pivots, 8 bytes a row -- lanes
+                // 0..31 fetch rows 2l, 2l + 1 (the planes are not padded: the upper half-wave stays out)
+                if (lane < 32) {
+                    const unsigned ro = (unsigned)((m0 + wm * WROWS + 2 * lane) * 8);
+#pragma unroll
+                    for (int c = 0; c < 16; ++c)
+                        dma16w(ldst + 2048 + c * 512, ro, reinterpret_cast<const char*>(p.lnf_partial + (size_t)c * p.lnf_partial_ld * 2));
+                    if (p.lnf_pivot) dma16w(ldst + 2048 + 8192, ro, reinterpret_cast<const char*>(p.lnf_pivot));
+                }
+                return;
+            }
+        }
         // lane l: rows 2l, 2l + 1 of the wave's (MI = 4: 64 rows past the wave's own ride along; the statistics buffer is padded by 256 rows)
         dma16w(ldst + 1024, (unsigned)((m0 + wm * WROWS + 2 * lane) * 8), reinterpret_cast<const char*>(p.lnf_stats));
+    };
+    // ... and turned into (mean, rstd) in front of the epilogue: lane l owns row l of the wave's 64, adds the planes in stats_finalize_kernel's order
+    // (lnf_stats_math.h: same bits), feeds the staging area the epilogue reads; feature tile 0 also stores them for the next producer (its pivots)
+    // and carries the fp16 range guard
+    [[maybe_unused]] auto finish_stats = [&]() {
+        if constexpr (MI == 4 && LNF) {
+            if (p.lnf_partial) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const f32x2 v = *reinterpret_cast<const f32x2*>(lnf_lds + 2048 + c * 512 + lane * 8);
+                    s1 += v[0];
+                    s2 += v[1];
+                }
+                const float pv = p.lnf_pivot ? *reinterpret_cast<const float*>(lnf_lds + 2048 + 8192 + lane * 8) : 0.0f;
+                float mean, rstd, sumsq;
+                lnf_row_stats(s1, s2, pv, p.K, mean, rstd, sumsq);
+                *reinterpret_cast<f32x2*>(lnf_lds + 1024 + lane * 8) = f32x2{mean, rstd};
+                if (p.lnf_stats_out && n0 == 0 && wn == 0) {
+                    const int m = m0 + wm * WROWS + lane;
+                    *reinterpret_cast<f32x2*>(p.lnf_stats_out + (size_t)m * 2) = f32x2{mean, rstd};
+                    lnf_raise_guard(p.lnf_sat, !(sumsq < 65504.0f * 65504.0f), sumsq, p.lnf_sat_tag, m + p.row0);
+                }
+            }
+        }
     };
     auto load_bias = [&](int tn0, f32x4 (&dst)[8]) {
 #pragma unroll
@@ -422,11 +480,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int pc = 0; pc < 8; ++pc) dma16w(X * OPB + wdstW + pc * 1024, voffW[pc], baseW);
     };
+    if constexpr (LNF) stage_lnf();  // (in front of the operand requests: the counted wait below then does not depend on how many it issues)
     issue_all(0);
     front_advance();
     issue_all(1);
     front_advance();
-    if constexpr (LNF) stage_lnf();
     f32x4 bstart[8];
     if constexpr (LNF) {
 #pragma unroll
@@ -436,7 +494,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     acc_from(bstart);
     if constexpr (EPI == EPI_RESID) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this thread's part of the bias / gate image is written)
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LNF ? NP + 5 : NP) : "memory");  // stage 0 has landed for everyone
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NP) : "memory");  // stage 0 has landed for everyone
     static_for<NR>([&](auto ec) { rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, ec); });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
@@ -477,6 +535,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and the stages requested ahead (and this tile's fold operands) have landed
             __builtin_amdgcn_sched_barrier(0);
+            finish_stats();
             if (p.act == ACT_GELU_TANH) {
                 store_half(X0{}, std::integral_constant<int, ACT_GELU_TANH>{});
                 store_half(X1{}, std::integral_constant<int, ACT_GELU_TANH>{});
@@ -496,12 +555,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if constexpr (LNF) stage_lnf();
         }
     }
+    if constexpr (MI == 4) {
+        if (((pfv[0] ^ pfv[1]) ^ (pfv[2] ^ pfv[3])) == 0x7fc0dead && (p.pf_n[0] | p.pf_n[1]) == 0xffffffffu) p.stats_out[0] = 0.f;  // (never true: keeps the prefetch loads alive)
+    }
 #undef W4_ACC
 #undef W4_DSR
 }
 }  // namespace
 
 int g_gemm_w4 = 1;  // tuning knob ("gemm_w4"): 1 = whole-tile block linears with enough tiles for the CUs (w4_tile_rows) run on the one-wave-per-SIMD kernel
+int g_gemm_w4_ink = 1;  // tuning knob ("gemm_w4_ink"): folded projections on the kernel's 128-row tiles finish the row statistics themselves (no statistics launch)
 int g_gemm_w4_bm = 0;  // diagnostic knob ("gemm_w4_bm"): token rows per tile, 0 = by tile count, 128 / 256 forced where the shape allows
 
 int gemm_persist_grid();  // gemm_fast.hip
@@ -522,12 +585,22 @@ static int w4_tile_rows(const GemmParams& p) {
     return 2 * t128 >= pg ? 128 : 0;
 }
 
+// LayerNorm fold: a consumer launch of this shape can finish the row statistics itself on this kernel (128-row tiles only: their stage buffers leave
+// the LDS for the 16 partial planes); dit_eval then drops the statistics launch in front of it
+bool gemm_w4_lnf_inkernel(int M, int N, int K) {
+    GemmParams t;
+    memset(&t, 0, sizeof(t));
+    t.M = M; t.N = N; t.K = K;
+    return g_gemm_w4 && g_gemm_w4_ink && K == 1024 && N % 256 == 0 && w4_tile_rows(t) == 128;
+}
+
 bool gemm_w4_ok(const GemmParams& p, int mode, int epi) {
     if (!g_gemm_w4 || mode != GEMM_DENSE) return false;
     if (p.N % 256 != 0 || p.K % 128 != 0 || p.K < 256 || (p.lda & 7) || (p.ldw & 7) || p.a_row_mod != 0 || p.row0 != 0) return false;
     if (w4_tile_rows(p) == 0) return false;  // small launches: the 8-wave kernel's narrower tiles
     if ((size_t)255 * (size_t)(p.lda > p.ldw ? p.lda : p.ldw) * 2 + 128 > 0x7fffffffull) return false;
-    if (p.lnf_partial || p.fin_counter || p.pf_n[0] || p.pf_n[1]) return false;
+    if (p.fin_counter) return false;  // (weight-prefetch ranges, pf_p: served by the 128-row tile, which is the one small launches take)
+    if (p.lnf_partial && !(w4_tile_rows(p) == 128 && p.lnf_stats && p.lnf_ncols == 16 && p.K == 1024 && p.lnf_partial_ld >= p.M)) return false;
     const bool lnf = p.lnf_stats != nullptr;
     if (epi == EPI_STORE_T || epi == EPI_ROPE_T) {
         if (!p.out_t || (p.ldo & 7) || !(p.act == ACT_NONE || p.act == ACT_GELU_TANH)) return false;

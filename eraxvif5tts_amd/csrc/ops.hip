@@ -417,7 +417,7 @@ extern "C" int f5_bench_mfma_rate(int random_operands, float* tflops, f5_stream_
 extern int g_sync_evals, g_attn_persist, g_attn_stagger, g_resid_rmw, g_ln_fold, g_ln_fold_inkernel, g_ln_fold_fin, g_gemm_pad_rows;
 extern int g_conv31_tok;
 extern int g_gemm_bm128, g_gemm_tile, g_gemm_group_sites, g_gemm_reverse_sites;
-extern int g_gemm_split_tail, g_gemm_w4, g_gemm_w4_bm;
+extern int g_gemm_split_tail, g_gemm_w4, g_gemm_w4_bm, g_gemm_w4_ink;
 extern int g_gemm_variant, g_gemm_group, g_gemm_persist_grid, g_gemm_persist, g_gemm_lean, g_ln_defer, g_ln_wide, g_ln_rows, g_ln_rows_min, g_w_prefetch, g_res_f16, g_conv31, g_attn_variant, g_vocos_fft;
 int g_tuning_epoch = 0;
 extern unsigned long long* g_attn_stamp_buf;
@@ -543,6 +543,10 @@ extern "C" int f5_tuning_set(const char* key, int value) {
     }
     if (strcmp(key, "gemm_split_tail") == 0) {
         g_gemm_split_tail = value != 0;
+        return 0;
+    }
+    if (strcmp(key, "gemm_w4_ink") == 0) {
+        g_gemm_w4_ink = value != 0;
         return 0;
     }
     if (strcmp(key, "gemm_w4_bm") == 0) {

@@ -211,6 +211,39 @@ def test_in_launch_row_statistics_equal_the_statistics_kernel(B, N):
     assert model.residual_fallbacks() == 0
 
 
+@pytest.mark.parametrize("B,N", [(1, 1024), (2, 1024), (1, 512)])
+def test_w4_kernel_finishes_the_row_statistics_itself(B, N):
+    """Small batches: a folded projection on the one-wave-per-SIMD kernel's 128-row tiles turns the producer's partial sums into (mean, rstd) itself
+    (knob gemm_w4_ink, on by default; csrc/gemm_w4.hip: finish_stats) -- no statistics launch in front of it.  Same arithmetic in the same order as
+    stats_finalize_kernel (lnf_stats_math.h), so sample() must not change by one bit against the statistics launches (gemm_w4_ink = 0) and against
+    the 8-wave kernel (gemm_w4 = 0), eager and graph replay."""
+    import bench
+    from eraxvif5tts_amd import _lib
+    from eraxvif5tts_amd.model import CFM, DiT
+    lib = _lib.load()
+    torch.manual_seed(4321)
+    model = bench.synth_weights(DiT(**bench.BASE_ARCH, text_num_embeds=bench.VOCAB, mel_dim=100, precision="bf16"), seed=0)
+    cfm = CFM(transformer=model, mel_spec_kwargs={"mel_spec_type": "vocos"}).cuda()
+    cond, text, lens, dur = bench.synth_batch(B, N, "cuda", seed=51)
+    y0 = torch.randn(B, N, 100, generator=torch.Generator().manual_seed(52))
+    kw = dict(cond=cond, text=text, duration=dur, lens=lens, steps=3, cfg_strength=2.0, sway_sampling_coef=-1.0, y0=y0, return_trajectory=False)
+    outs = {}
+    for tag, knobs in (("ink", {}), ("launches", {"gemm_w4_ink": 0}), ("8wave", {"gemm_w4": 0})):
+        for k, v in knobs.items():
+            _lib.check(lib.f5_tuning_set(k.encode(), v))
+        try:
+            outs[tag] = cfm.sample(use_graph=False, **kw)[0].cpu()
+            if tag == "ink":
+                for _ in range(2):
+                    assert torch.equal(cfm.sample(use_graph=True, **kw)[0].cpu(), outs[tag])
+        finally:
+            for k in knobs:
+                _lib.check(lib.f5_tuning_set(k.encode(), 1))
+    assert torch.isfinite(outs["ink"]).all()
+    assert torch.equal(outs["ink"], outs["launches"]) and torch.equal(outs["ink"], outs["8wave"])
+    assert model.residual_fallbacks() == 0
+
+
 def test_fold_tables_follow_the_time_grid_across_graphs_and_streams():
     """The LayerNorm-fold tables are per TIME GRID, owned by the model (at most two), shared by its plans, and captured graphs bake their addresses:
     alternate three grids (NFE 3 / 4 / 5: the third evicts the first) with hipGraph replay on two streams, F5TTS_Base width at depth 4 -- every
