@@ -91,9 +91,9 @@ int dit_eval(f5_plan_s* p, const float* x, int xrows, int nb, int N, const float
         GemmParams t = gp_zero();
         t.M = rows_g; t.K = D; t.lda = D; t.ldw = D;
         t.N = 3 * inner;
-        if (!ink_qkv && gemm_w4_lnf_inkernel(rows_g, 3 * inner, D) && gemm_fast_lnf_inkernel(t)) ink_qkv = true;
+        if (!ink_qkv && gemm_w4_lnf_inkernel(rows_g, 3 * inner, D) != 0 && gemm_fast_lnf_inkernel(t)) ink_qkv = true;
         t.N = ff;
-        if (!ink_ff1 && gemm_w4_lnf_inkernel(rows_g, ff, D) && gemm_fast_lnf_inkernel(t)) ink_ff1 = true;
+        if (!ink_ff1 && gemm_w4_lnf_inkernel(rows_g, ff, D) != 0 && gemm_fast_lnf_inkernel(t)) ink_ff1 = true;
     }
     // producer side of site k (out-projection, FF2): the non-persistent schedules (small batches) finish the statistics inside the launch -- the
     // workgroup that completes a block of token rows last turns the partial sums into (mean, rstd), carries the range guard and leaves nothing

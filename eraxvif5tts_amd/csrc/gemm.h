@@ -108,7 +108,7 @@ bool gemm_fast_resid_finishes(const GemmParams& p);
 // true when a dense launch with these parameters runs on the one-wave-per-SIMD kernel (gemm_w4.hip): whole tiles, at least one per CU, lean operand forms
 bool gemm_w4_ok(const GemmParams& p, int mode, int epi);
 // LayerNorm fold: a folded projection of this shape finishes the row statistics inside the one-wave-per-SIMD kernel (128-row tiles)
-bool gemm_w4_lnf_inkernel(int M, int N, int K);
+int gemm_w4_lnf_inkernel(int M, int N, int K);  // 0, or the tile height (128) that finishes them
 // dedicated kernel for the dim-1024 grouped Conv1d(k = 31) of ConvPositionEmbedding (conv31.hip); GemmParams as for GEMM_CONV31
 bool conv31_supported(const GemmParams& p, int precision, int epi);
 int launch_conv31(const GemmParams& p, hipStream_t stream);

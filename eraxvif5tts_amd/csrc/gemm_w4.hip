@@ -237,6 +237,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ... and turned into (mean, rstd) in front of the epilogue: lane l owns row l of the wave's 64, adds the planes in stats_finalize_kernel's order
     // (lnf_stats_math.h: same bits), feeds the staging area the epilogue reads; feature tile 0 also stores them for the next producer (its pivots)
     // and carries the fp16 range guard
+    // (The 256-row tile has no LDS for the planes.  Tried: lane l loads rows 2l, 2l + 1 of all 16 planes into registers behind the main loop, for
+    //  launches with at most two tiles per CU -- 4 x 1024: 27 980 -> 27 880 mel-frames/s, 3 x 1024: 23 080 -> 22 450: the exposed memory latency per
+    //  tile costs what the two statistics launches cost.  profiles/r4_w4_inkernel_statistics_256_row_tiles_tried.txt.  Removed.)
     [[maybe_unused]] auto finish_stats = [&]() {
         if constexpr (MI == 4 && LNF) {
             if (p.lnf_partial) {
@@ -585,13 +588,16 @@ static int w4_tile_rows(const GemmParams& p) {
     return 2 * t128 >= pg ? 128 : 0;
 }
 
-// LayerNorm fold: a consumer launch of this shape can finish the row statistics itself on this kernel (128-row tiles only: their stage buffers leave
-// the LDS for the 16 partial planes); dit_eval then drops the statistics launch in front of it
-bool gemm_w4_lnf_inkernel(int M, int N, int K) {
+// LayerNorm fold: a consumer launch of this shape can finish the row statistics itself on this kernel -- returns the tile height that does (128: the
+// partial planes travel through the LDS the short tile's stage buffers leave), 0 otherwise; dit_eval then drops the statistics launch in front of it
+int gemm_w4_lnf_inkernel(int M, int N, int K) {
     GemmParams t;
     memset(&t, 0, sizeof(t));
     t.M = M; t.N = N; t.K = K;
-    return g_gemm_w4 && g_gemm_w4_ink && K == 1024 && N % 256 == 0 && w4_tile_rows(t) == 128;
+    if (!g_gemm_w4 || !g_gemm_w4_ink || K != 1024 || N % 256 != 0) return 0;
+    const int rows = w4_tile_rows(t);
+    if (rows == 128) return 128;
+    return 0;
 }
 
 bool gemm_w4_ok(const GemmParams& p, int mode, int epi) {
@@ -600,7 +606,7 @@ bool gemm_w4_ok(const GemmParams& p, int mode, int epi) {
     if (w4_tile_rows(p) == 0) return false;  // small launches: the 8-wave kernel's narrower tiles
     if ((size_t)255 * (size_t)(p.lda > p.ldw ? p.lda : p.ldw) * 2 + 128 > 0x7fffffffull) return false;
     if (p.fin_counter) return false;  // (weight-prefetch ranges, pf_p: served by the 128-row tile, which is the one small launches take)
-    if (p.lnf_partial && !(w4_tile_rows(p) == 128 && p.lnf_stats && p.lnf_ncols == 16 && p.K == 1024 && p.lnf_partial_ld >= p.M)) return false;
+    if (p.lnf_partial && !(gemm_w4_lnf_inkernel(p.M, p.N, p.K) != 0 && p.lnf_stats && p.lnf_ncols == 16 && p.lnf_partial_ld >= p.M)) return false;
     const bool lnf = p.lnf_stats != nullptr;
     if (epi == EPI_STORE_T || epi == EPI_ROPE_T) {
         if (!p.out_t || (p.ldo & 7) || !(p.act == ACT_NONE || p.act == ACT_GELU_TANH)) return false;

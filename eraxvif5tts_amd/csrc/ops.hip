@@ -546,7 +546,7 @@ extern "C" int f5_tuning_set(const char* key, int value) {
         return 0;
     }
     if (strcmp(key, "gemm_w4_ink") == 0) {
-        g_gemm_w4_ink = value != 0;
+        g_gemm_w4_ink = value;
         return 0;
     }
     if (strcmp(key, "gemm_w4_bm") == 0) {

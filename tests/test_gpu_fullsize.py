@@ -211,10 +211,11 @@ def test_in_launch_row_statistics_equal_the_statistics_kernel(B, N):
     assert model.residual_fallbacks() == 0
 
 
-@pytest.mark.parametrize("B,N", [(1, 1024), (2, 1024), (1, 512)])
+@pytest.mark.parametrize("B,N", [(1, 1024), (2, 1024), (1, 512), (4, 1024), (5, 1024)])
 def test_w4_kernel_finishes_the_row_statistics_itself(B, N):
-    """Small batches: a folded projection on the one-wave-per-SIMD kernel's 128-row tiles turns the producer's partial sums into (mean, rstd) itself
-    (knob gemm_w4_ink, on by default; csrc/gemm_w4.hip: finish_stats) -- no statistics launch in front of it.  Same arithmetic in the same order as
+    """Small batches: a folded projection on the one-wave-per-SIMD kernel's 128-row tiles (1 - 2 utterances) turns the producer's partial sums into
+    (mean, rstd) itself (knob gemm_w4_ink, on by default; csrc/gemm_w4.hip: finish_stats) -- no statistics launch in front of it; 4 - 5 utterances
+    take 256-row tiles and keep the launch.  Same arithmetic in the same order as
     stats_finalize_kernel (lnf_stats_math.h), so sample() must not change by one bit against the statistics launches (gemm_w4_ink = 0) and against
     the 8-wave kernel (gemm_w4 = 0), eager and graph replay."""
     import bench
@@ -238,7 +239,7 @@ def test_w4_kernel_finishes_the_row_statistics_itself(B, N):
                     assert torch.equal(cfm.sample(use_graph=True, **kw)[0].cpu(), outs[tag])
         finally:
             for k in knobs:
-                _lib.check(lib.f5_tuning_set(k.encode(), 1))
+                _lib.check(lib.f5_tuning_set(k.encode(), {"gemm_w4_ink": 1, "gemm_w4": 1}[k]))
     assert torch.isfinite(outs["ink"]).all()
     assert torch.equal(outs["ink"], outs["launches"]) and torch.equal(outs["ink"], outs["8wave"])
     assert model.residual_fallbacks() == 0
