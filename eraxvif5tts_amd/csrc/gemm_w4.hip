@@ -6,7 +6,7 @@
 // 32 -- a third less LDS traffic per FLOP -- and whole 128-byte lines per LDS-DMA row instead of half lines.  Round 1 had tried this tile shape with
 // compiler-scheduled code and lost (every stall of a lone wave is exposed); here every non-MFMA instruction of the main loop is PLACED BY HAND
 // between the MFMAs (inline asm, hand-counted s_waitcnt), which is what makes the shape pay: tools/gemm_w4_probe.hip developed the schedule
-// (8192^3: 1 490 TFLOP/s against 1 320 for the vendor kernel on the same box; LDS bank conflicts 0).
+// (8192^3: 1 490 - 1 550 TFLOP/s against 1 320 for the vendor kernel on the same box; LDS bank conflicts 0).
 //
 // Structure:
 //   * persistent grid, one 256-thread workgroup per CU, 256 x 256 output tile, wave w owns tokens (w >> 1) * 128.., features (w & 1) * 128..;
@@ -21,8 +21,10 @@
 //   * same MFMA (weights on the row index), same K order, same start value (bias, or 0 under the LayerNorm fold) and the same epilogue arithmetic
 //     as gemm_fast.hip's persistent build: a wave's 128 features are treated as two 64-feature halves = two "waves" of that kernel, so the output
 //     bits do not depend on which of the two kernels a launch takes (tests/test_gpu_ops.py::test_w4_kernel_equals_the_8_wave_kernel).
-// Launch conditions (launch_gemm_w4_ok): bf16 / fp16-fold operands, M % 256 == 0, N % 256 == 0, K % 128 == 0, K >= 256, the lean operand forms
-// of the persistent 8-wave build, and enough tiles for the CUs (w4_tile_rows: 256-row tiles from three quarters of the CUs on, else 128-row tiles from half).
+//   * a second tile height (template parameter MI = 4: 128 x 256, 64 x 128 per wave) for small batches; there the folded projections also finish the
+//     LayerNorm fold's row statistics themselves (finish_stats) and the kernel touches the weights of the launches behind it.
+// Launch conditions (gemm_w4_ok): bf16 / fp16-fold operands, M % 128 == 0, N % 256 == 0, K % 128 == 0, K >= 256, the lean operand forms of the
+// persistent 8-wave build, and enough tiles for the CUs (w4_tile_rows: 256-row tiles from three quarters of the CUs on, else 128-row tiles from half).
 #include "gemm_tile.h"
 #include "lnf_stats_math.h"
 #include <string.h>
