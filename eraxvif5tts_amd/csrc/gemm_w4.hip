@@ -169,7 +169,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto body = [&](auto xc, auto waitc) {
         constexpr int X = decltype(xc)::value;
         constexpr bool WAITV = decltype(waitc)::value;
-        // (MI = 4, 64 MFMAs: 12 reads in slots 0..11, B1 behind 13, 12 requests at 14, 18, .. 58, B2 behind 42, the next reads at 44..55)
+        // (MI = 4, 64 MFMAs: 12 reads in slots 0..11, B1 behind 13, 12 requests at 14, 18, .. 58, B2 behind 42, the next reads at 44..55; requests every 3
+        //  MFMAs, or everything two slots later: no difference at 1 / 2 / 4 utterances, profiles/r4_w4_128_row_schedule_variants.txt)
         constexpr int R1S = 1, B1P = MI == 8 ? 20 : 13, D0 = MI == 8 ? 22 : 14, DS = MI == 8 ? 6 : 4, B2P = MI == 8 ? 86 : 42, R0 = MI == 8 ? 88 : 44,
                       R0S = MI == 8 ? 2 : 1;
         static_for<NMF>([&](auto nc) {
