@@ -86,8 +86,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     front_tile();
     const int wdst = wave * 8192;  // this wave's pieces inside an operand buffer
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
     auto dma = [&](int ldsdst, unsigned voff, const char* base) {
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsdst), "v"(voff), "s"(base) : "memory");
+        if constexpr (SCHED == 60) {  // the vendor kernel's request form: buffer_load ... lds through a raw buffer descriptor (base, no stride, 4 GiB, dword3 0x00020000)
+            const unsigned long long b = (unsigned long long)base;
+            const i32x4 rsrc = {(int)(unsigned)b, (int)(unsigned)(b >> 32) & 0xffff, -1, 0x00020000};
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(ldsdst), "v"(voff), "s"(rsrc) : "memory");
+        } else {
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsdst), "v"(voff), "s"(base) : "memory");
+        }
     };
     auto front_advance = [&]() {
         ++f_g;
@@ -142,8 +149,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // with that start skew; 20: schedule 1 without the stores
         constexpr bool NO_DMA = SCHED == 10 || SCHED == 12 || SCHED == 13 || SCHED == 17 || SCHED == 18, NO_RD = SCHED == 11 || NO_DMA && SCHED != 10, NO_BAR = SCHED == 13 || SCHED == 14 || SCHED == 17 || SCHED == 18;
         constexpr bool M0E = SCHED == 40 || SCHED == 41;
-        constexpr bool S42 = (SCHED >= 42 && SCHED <= 47) || SCHED == 50 || SCHED == 51;  // family of schedule 42: reads of sub-step 1 in the first 16 slots, requests spread wide
-        constexpr int R1S = SCHED == 0 ? 3 : (S42 ? 1 : 2), B1P = SCHED == 0 ? 49 : (S42 ? ((SCHED == 46 || SCHED == 50) ? 20 : 24) : 40), D0 = SCHED == 0 ? 50 : (S42 ? ((SCHED == 46 || SCHED == 50) ? 22 : 26) : 42), DS = (SCHED == 2 || SCHED == 4 || SCHED == 41) ? 2 : (SCHED == 43 ? 5 : (SCHED == 44 || SCHED == 46 || SCHED == 50 ? 6 : (S42 ? 4 : 3)));
+        constexpr bool S42 = (SCHED >= 42 && SCHED <= 47) || SCHED == 50 || SCHED == 51 || SCHED == 60;  // family of schedule 42: reads of sub-step 1 in the first 16 slots, requests spread wide
+        constexpr int R1S = SCHED == 0 ? 3 : (S42 ? 1 : 2), B1P = SCHED == 0 ? 49 : (S42 ? ((SCHED == 46 || SCHED == 50 || SCHED == 60) ? 20 : 24) : 40), D0 = SCHED == 0 ? 50 : (S42 ? ((SCHED == 46 || SCHED == 50 || SCHED == 60) ? 22 : 26) : 42), DS = (SCHED == 2 || SCHED == 4 || SCHED == 41) ? 2 : (SCHED == 43 ? 5 : (SCHED == 44 || SCHED == 46 || SCHED == 50 || SCHED == 60 ? 6 : (S42 ? 4 : 3)));
         constexpr int B2P = SCHED == 0 ? 100 : (SCHED == 3 || SCHED == 4 ? 78 : (SCHED == 45 ? 104 : (SCHED == 47 ? 94 : 86))), R0 = B2P + 2, R0S = SCHED == 0 ? 0 : (SCHED == 45 ? 1 : 2);
         static_for<128>([&](auto nc) {
             (void)acc; (void)fw; (void)fa;
@@ -384,7 +391,7 @@ static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u
 
 static void launch(int sched, dim3 grid, const bf16_t* dA, const bf16_t* dW, bf16_t* dC, int M, int N, int K, int tiles_n, int nblocks) {
 #define W4_CASE(S) case S: hipLaunchKernelGGL(w4_kernel<S>, grid, dim3(256), 0, 0, dA, dW, dC, M, N, K, K, K, N, tiles_n, nblocks, 8); break;
-    switch (sched) { W4_CASE(0) W4_CASE(1) W4_CASE(3) W4_CASE(10) W4_CASE(11) W4_CASE(12) W4_CASE(13) W4_CASE(14) W4_CASE(17) W4_CASE(18) W4_CASE(19) W4_CASE(20) W4_CASE(21) W4_CASE(22) W4_CASE(23) W4_CASE(30) W4_CASE(31) W4_CASE(32) W4_CASE(33) W4_CASE(40) W4_CASE(41) W4_CASE(42) W4_CASE(43) W4_CASE(44) W4_CASE(45) W4_CASE(46) W4_CASE(47) W4_CASE(50) }
+    switch (sched) { W4_CASE(0) W4_CASE(1) W4_CASE(3) W4_CASE(10) W4_CASE(11) W4_CASE(12) W4_CASE(13) W4_CASE(14) W4_CASE(17) W4_CASE(18) W4_CASE(19) W4_CASE(20) W4_CASE(21) W4_CASE(22) W4_CASE(23) W4_CASE(30) W4_CASE(31) W4_CASE(32) W4_CASE(33) W4_CASE(40) W4_CASE(41) W4_CASE(42) W4_CASE(43) W4_CASE(44) W4_CASE(45) W4_CASE(46) W4_CASE(47) W4_CASE(50) W4_CASE(60) }
 }
 
 int main(int argc, char** argv) {
@@ -394,7 +401,7 @@ int main(int argc, char** argv) {
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     ncu = prop.multiProcessorCount & ~7;
-    for (int sched : {46, 50, 46, 50})
+    for (int sched : {46, 60, 46, 60})
     for (const Shape& sh : shapes) {
         const int M = sh.M, N = sh.N, K = sh.K;
         std::vector<uint16_t> hA((size_t)M * K), hW((size_t)N * K);
