@@ -5,6 +5,17 @@
 // The vendor library's best kernel for these shapes has this shape (hipBLASLt "MT256x256x64 ... 4 waves"; measured 17 - 22 % faster than the
 // 8-wave staggered kernel of gemm_fast.hip at the four call sites); this file is where the schedule was developed before it moved into the library.
 //   hipcc -O3 --offload-arch=gfx950 tools/gemm_w4_probe.hip -o tools/bin/gemm_w4_probe && tools/bin/gemm_w4_probe
+// Schedules (template parameter SCHED; main() runs the list in its `for (int sched : {...})`; results under profiles/r4_w4_probe_*.txt):
+//    0        first schedule: reads every 3rd MFMA slot, B1 behind 49, requests every 3 from 50, B2 behind 100
+//    1 / 3    reads every 2nd slot, B1 behind 40, requests every 3 from 42, B2 behind 86 / 78           (the library's first build)
+//    2 / 4    the same with requests every 2 slots                                                     (slower)
+//   10 .. 14  timing-only ablations of schedule 1: no requests / no fragment reads / neither / MFMA stream alone / no barriers
+//   17 .. 23  store experiments: no stores (17, 20), half-tile start skew of every other workgroup (18, 19), non-temporal stores (22)
+//   30 .. 33  read-modify-write epilogue (the in-place residual update): all loads first / with skew / loads only / step-wise
+//   40, 41    M0 written one slot ahead of its request (no effect); 41 also requests every 2 slots
+//   42 .. 47  sub-step-1 reads in the first 16 slots, requests spread wide (every 4 - 6 slots); 46 = the library's schedule
+//   50        deferred stores: half of a tile's packed output leaves during the next tile's first four iterations (slower)
+//   60        schedule 46 with the vendor kernel's request form, buffer_load_dwordx4 ... offen lds (no difference)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
